@@ -1,0 +1,199 @@
+/*
+ * tomo_mi355x.h -- C-ABI of libtomo_mi355x.so: the MI355X (gfx950) drop-in for the
+ * ordered-subsets FISTA / ADMM hot path of ToMoBAR (parallel-beam 3D forward / back
+ * projection, data-fidelity gradient, TV proximal operators and the element-wise glue).
+ *
+ * Conventions
+ *   - every pointer named *_dev is a caller-owned DEVICE pointer to C-contiguous float32;
+ *     the library owns only opaque contexts (geometry tables, grow-only scratch arena);
+ *   - volume  layout [nz][n][n]   (z, y, x)   -- astra.geom_size(vol_geom),  astra_base.py:215-222,547
+ *   - sinogram layout [nz][na][nu] (detY, angles, detX)                   -- dicts.py:50, astra_base.py:247-252,592
+ *   - voxel (ix,iy,iz) centre at (ix-n/2+1/2, iy-n/2+1/2, iz-nz/2+1/2), unit voxels, no axis flips;
+ *     detector pixel iu at signed offset cor + iu - nu/2 + 1/2 along u=(cos t, sin t, 0); rays (sin t, -cos t, 0)
+ *     (tomobar/supp/funcs.py:45-65); detector row iv == volume slice iz;
+ *   - every entry point is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *     unless it returns a scalar to the host (tomo_norm2, tomo_max);
+ *   - return value 0 = ok; otherwise a TOMO_E_* code and tomo_last_error() (thread-local) describes it.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to /root/reference).
+ */
+#ifndef TOMO_MI355X_H
+#define TOMO_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TOMO_ABI_VERSION 1
+
+enum {
+    TOMO_OK = 0,
+    TOMO_E_INVALID = 1,  /* bad argument: maps to ValueError in the Python layer */
+    TOMO_E_RUNTIME = 2,  /* HIP runtime failure */
+    TOMO_E_NOMEM = 3,
+    TOMO_E_NODEVICE = 4  /* no usable gfx950 device: the product path fails loudly, there is no CPU fallback */
+};
+
+/* ctx flags */
+#define TOMO_FLAG_LERP8 1u /* quantise interpolation weights to 8 fractional bits (NVIDIA texture-unit emulation) */
+
+/* data fidelity selector of tomobar/data_fidelities.py:28-39;
+ * TOMO_FID_RATIO = b / max(Ax, 1e-8), the OSEM ratio of methodsIR_CuPy.py:648-650 */
+enum { TOMO_FID_LS = 0, TOMO_FID_PWLS = 1, TOMO_FID_KL = 2, TOMO_FID_RATIO = 3 };
+
+typedef struct tomo_ctx tomo_ctx;
+
+/* per-angle geometry record (host-visible copy of the device table) */
+typedef struct {
+    float cs, sn;   /* (float)cos(theta), (float)sin(theta) */
+    float cor;      /* horizontal CoR offset */
+    float slope;    /* FP: d(interp coordinate)/d(step) */
+    float inv;      /* FP: 1/sin (x-stepping) or 1/cos (y-stepping) */
+    float scale;    /* FP: ray length per step */
+    int32_t dirx;   /* FP: 1 = step along x / interpolate along y */
+    int32_t src;    /* index into the full sinogram's angle axis */
+} tomo_angle_t;
+
+int tomo_abi_version(void);
+const char *tomo_last_error(void);
+int tomo_device_count(int *count);
+
+/* ---------------------------------------------------------------- context / geometry
+ * Replaces AstraTools3D.__init__ -> AstraBase._set_vol3d_geometry (astra_base.py:215-222),
+ * _set_gpu_projection3d_parallel_geometry (:244-255), _setOS_indices (:195-209) and
+ * _set_projection3d_OS_parallel_geometry (:287-308); geometry vectors of supp/funcs.py:45-65.
+ * angles_host [na] radians (float64).  cor_host: cor_stride==0 -> one scalar; ==1 -> [na];
+ * ==2 -> [na][2] (horizontal, vertical) where the vertical component must be 0.
+ * Nothing is created per call afterwards (the reference re-creates an ASTRA projector per call,
+ * astra_base.py:538-545,586-604). */
+int tomo_ctx_create(int device, int nz, int n, int nu, int na, const double *angles_host,
+                    const double *cor_host, int cor_stride, int os_number, unsigned flags,
+                    tomo_ctx **out);
+int tomo_ctx_destroy(tomo_ctx *ctx);
+int tomo_ctx_os_number(const tomo_ctx *ctx);
+int tomo_ctx_num_bins(const tomo_ctx *ctx);                       /* AstraBase.NumbProjBins */
+/* AstraBase.newInd_Vec, [os_number][num_bins] int64, zero-filled tail (astra_base.py:199-209) */
+int tomo_ctx_newind_table(const tomo_ctx *ctx, int64_t *out_host);
+/* subset = -1 -> all angles.  Size after the one-element trim of methodsIR_CuPy.py:454-456. */
+int tomo_ctx_subset_size(const tomo_ctx *ctx, int subset);
+int tomo_ctx_angle_table(const tomo_ctx *ctx, int subset, tomo_angle_t *out_host, int capacity);
+/* release the context's scratch arena (cp._default_memory_pool.free_all_blocks(), methodsIR_CuPy.py:425) */
+int tomo_ctx_release_scratch(tomo_ctx *ctx);
+
+/* ---------------------------------------------------------------- projector pair
+ * tomo_fp3d  replaces AstraBase.runAstraProj3DCuPy  (astra_base.py:560-606, direct_FP3D :601)
+ *            reached through AstraTools3D._forwprojCuPy/_forwprojOSCuPy (astra_tools3d.py:78-86).
+ * tomo_bp3d  replaces AstraBase.runAstraBackproj3DCuPy (astra_base.py:518-558, direct_BP3D :554)
+ *            reached through _backprojCuPy/_backprojOSCuPy (astra_tools3d.py:102-110).
+ * sino_dev is [nz][subset_size][nu]; both outputs are fully overwritten. */
+int tomo_fp3d(tomo_ctx *ctx, int subset, const float *vol_dev, float *sino_dev, void *stream);
+int tomo_bp3d(tomo_ctx *ctx, int subset, const float *sino_dev, float *vol_dev, void *stream);
+
+/* ---------------------------------------------------------------- fused data-fidelity gradient
+ * tomo_fp3d_residual: res = w_s (.) (A_s x - b_s)  [LS/PWLS]   or   1 - b_s / max(A_s x, 1e-8)  [KL]
+ *   i.e. data_fidelities.py:28-39 with the subset gather b[:, indVec, :] of methodsIR_CuPy.py:457
+ *   done by index inside the kernel.  b_dev / w_dev are FULL sinograms [nz][na][nu] by default;
+ *   `gathered` bit 0 / bit 1 says that b_dev / w_dev is already the subset's [nz][subset_size][nu]
+ *   (the form grad_data_term receives, data_fidelities.py:7-14).  w_dev may be NULL (LS).
+ *   res_dev is [nz][subset_size][nu]. */
+#define TOMO_GATHERED_B 1
+#define TOMO_GATHERED_W 2
+int tomo_fp3d_residual(tomo_ctx *ctx, int subset, const float *vol_dev, const float *b_dev,
+                       const float *w_dev, int gathered, int fidelity, float *res_dev, void *stream);
+
+/* tomo_bp3d_fista: x_out = P+( x_t - l_inv * A_s^T res )            methodsIR_CuPy.py:463-468
+ *   nonneg != 0 applies the max(.,0) projection.  x_out may alias x_t. */
+int tomo_bp3d_fista(tomo_ctx *ctx, int subset, const float *res_dev, const float *xt_dev,
+                    float *xout_dev, float l_inv, int nonneg, void *stream);
+/* tomo_bp3d_fista_momentum (no proximal operator between gradient step and momentum):
+ *   X = P+(X_t - l_inv*A_s^T res);  X_t <- X + beta*(X - X_old);   methodsIR_CuPy.py:463-475
+ *   on entry xold_x_dev holds X_old, on exit X;  xt_dev holds X_t on entry and the new X_t on exit. */
+int tomo_bp3d_fista_momentum(tomo_ctx *ctx, int subset, const float *res_dev, float *xt_dev,
+                             float *xold_x_dev, float l_inv, float beta, int nonneg, void *stream);
+/* tomo_bp3d_admm:  g = A_s^T res;  z <- z - tau*(g + rho*(z - x + u));  optional max(.,0);
+ *   if relax_on:  z <- (1-alpha)*z_start + alpha*z;   zu_out = z + u     methodsIR_CuPy.py:545-557
+ *   (z_old of the reference equals z at the start of the sub-iteration, :555).
+ *   one_minus_alpha / alpha are passed pre-rounded to float32 by the caller. */
+int tomo_bp3d_admm(tomo_ctx *ctx, int subset, const float *res_dev, float *z_dev, const float *x_dev,
+                   const float *u_dev, float *zu_out_dev, float tau, float rho, int relax_on,
+                   float one_minus_alpha, float alpha, int nonneg, void *stream);
+
+/* ---------------------------------------------------------------- element-wise glue
+ * tomo_momentum : x_t = x + beta*(x - x_old)                         methodsIR_CuPy.py:475
+ * tomo_admm_dual: u  += z - x                                        methodsIR_CuPy.py:566
+ * tomo_axpby    : y   = a*x + b*y   (Landweber / SIRT / CGLS updates, methodsIR_CuPy.py:165,222,285-295)
+ * tomo_scale    : y   = a*x                                          methodsIR_CuPy.py:337
+ * tomo_clamp_min: x   = max(x, lo)                                   methodsIR_CuPy.py:468,549
+ * tomo_mul      : y   = x*y ;  tomo_recip_safe: y = 1/x with nan/inf -> 1 (SIRT, :206-214)
+ * tomo_norm2    : sqrt(sum x^2) -> host (cp.linalg.norm,            methodsIR_CuPy.py:336,349)
+ * tomo_dot      : sum x*y -> host (cp.inner, :272,284,292);  tomo_max: max -> host (:395)
+ * tomo_pwls_weights: w = max(b,1e-6) / max(max(b,1e-6))              methodsIR_CuPy.py:392-395 */
+int tomo_momentum(const float *x_dev, const float *xold_dev, float *xt_dev, float beta, size_t count, void *stream);
+int tomo_admm_dual(float *u_dev, const float *z_dev, const float *x_dev, size_t count, void *stream);
+int tomo_axpby(float a, const float *x_dev, float b, float *y_dev, size_t count, void *stream);
+int tomo_scale(float a, const float *x_dev, float *y_dev, size_t count, void *stream);
+int tomo_clamp_min(float *x_dev, float lo, size_t count, void *stream);
+int tomo_mul(const float *x_dev, float *y_dev, size_t count, void *stream);
+int tomo_recip_safe(const float *x_dev, float *y_dev, size_t count, void *stream);
+int tomo_fill(float *x_dev, float value, size_t count, void *stream);
+int tomo_norm2(const float *x_dev, size_t count, double *out_host, void *stream);
+int tomo_dot(const float *x_dev, const float *y_dev, size_t count, double *out_host, void *stream);
+int tomo_max(const float *x_dev, size_t count, float *out_host, void *stream);
+int tomo_pwls_weights(const float *b_dev, float *w_dev, size_t count, void *stream);
+
+/* ---------------------------------------------------------------- pre/post glue
+ * tomo_pad_edge   : edge-pad detX by `pad` both sides, [nz][na][nu0] -> [nz][na][nu0+2pad]
+ *                   (_apply_horiz_detector_padding, supp/suppTools.py:425-459)
+ * tomo_crop_center: centre-crop y,x  [nz][n][n] -> [nz][m][m]  (perform_recon_crop, suppTools.py:399-422)
+ * tomo_circ_mask  : in-place disc mask of apply_circular_mask (suppTools.py:364-396)
+ * tomo_permute3   : out[i][j][k] = in laid out with strides (s0,s1,s2) -- materialises the axis swap of
+ *                   _data_dims_swapper (supp/funcs.py:190-206) as a contiguous array */
+int tomo_pad_edge(const float *in_dev, float *out_dev, int rows, int nu0, int pad, void *stream);
+int tomo_crop_center(const float *in_dev, float *out_dev, int nz, int n, int m, void *stream);
+int tomo_circ_mask(float *vol_dev, int nz, int n, double radius, void *stream);
+int tomo_permute3(const float *in_dev, float *out_dev, int d0, int d1, int d2,
+                  int64_t s0, int64_t s1, int64_t s2, void *stream);
+
+/* ---------------------------------------------------------------- TV proximal operators
+ * tomo_pdtv replaces PD_TV_cupy's device work (regularisersCuPy.py:220-296) and the 16 kernels
+ *   primal_dual_for_total_variation_{2D,3D}_{float,half}[_nonneg][_methodTV]
+ *   (cuda_kernels/primal_dual_for_total_variation.cu:263-301,454-492).
+ *   dims: dx fastest.  nd = 2 -> [dy][dx] (dz ignored), nd = 3 -> [dz][dy][dx].
+ *   sigma,tau,lt,theta are the float32 scalars of regularisersCuPy.py:215-218 (computed by the caller).
+ *   half != 0 stores the dual fields as IEEE binary16.  out_dev receives U_arrays[iters % 2].
+ * tomo_roftv replaces ROF_TV_cupy's device work (regularisersCuPy.py:78-167) and
+ *   divergence_kernel_* / TV_kernel_* (cuda_kernels/rudin_osher_fatemi_total_variation.cu:106-148,203-248);
+ *   the two kernels are fused (the D fields never reach HBM); half != 0 rounds D through binary16.
+ * `device` selects the GPU (gpu_id argument of the reference functions). */
+int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx, int dy, int dz, int nd,
+              float sigma, float tau, float lt, float theta, int iters, int methodTV, int nonneg,
+              int half, void *stream);
+int tomo_roftv(int device, const float *in_dev, float *out_dev, int dx, int dy, int dz, int nd,
+               float lambda, float tau, int iters, int half, void *stream);
+/* scratch bytes the TV drivers hold for a given problem (informational) and arena release */
+size_t tomo_pdtv_scratch_bytes(int dx, int dy, int dz, int nd, int half);
+size_t tomo_roftv_scratch_bytes(int dx, int dy, int dz, int nd);
+int tomo_release_scratch(int device);
+
+/* Slab (multi-GPU) form of one PD-TV iteration on arrays that carry ghost planes:
+ *   every array pointer addresses [has_lo + nz_local + has_hi][dy][dx]; the planes at either end are
+ *   the neighbours' boundary planes (read-only).  Boundary rules (zIndex>0 / last_z of
+ *   primal_dual_for_total_variation.cu:188,213) apply only where has_lo/has_hi == 0. */
+int tomo_pdtv_iter_slab(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
+                        const void *p_in_dev[3], void *p_out_dev[3], int dx, int dy, int nz_local,
+                        int has_lo, int has_hi, float sigma, float tau, float lt, float theta,
+                        int methodTV, int nonneg, int half, void *stream);
+int tomo_roftv_iter_slab(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
+                         int dx, int dy, int nz_local, int lo_planes, int hi_planes,
+                         float lambda, float tau, int half, void *stream);
+
+/* kernel-variant selector for A/B measurement: name in {"bp","fp","pdtv","roftv"}; variant 0 = default */
+int tomo_set_variant(const char *kernel, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOMO_MI355X_H */

@@ -1,0 +1,109 @@
+"""ctypes binding of ``libtomo_mi355x.so`` (the C-ABI declared in ``include/tomo_mi355x.h``).
+
+There is deliberately no fallback: if the shared library is missing or no gfx950 device is
+visible, every operator raises.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C tomobar_amd/csrc``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtomo_mi355x.so")
+
+OK, E_INVALID, E_RUNTIME, E_NOMEM, E_NODEVICE = 0, 1, 2, 3, 4
+FLAG_LERP8 = 1
+FID = {"LS": 0, "PWLS": 1, "KL": 2, "RATIO": 3}
+
+
+class AngleRecord(C.Structure):
+    _fields_ = [("cs", C.c_float), ("sn", C.c_float), ("cor", C.c_float), ("slope", C.c_float),
+                ("inv", C.c_float), ("scale", C.c_float), ("dirx", C.c_int32), ("src", C.c_int32)]
+
+
+_vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); kept in one table so tests can check it against the header
+SIGNATURES = {
+    "tomo_abi_version": (_i, []),
+    "tomo_last_error": (C.c_char_p, []),
+    "tomo_device_count": (_i, [C.POINTER(_i)]),
+    "tomo_ctx_create": (_i, [_i, _i, _i, _i, _i, C.POINTER(_d), C.POINTER(_d), _i, _i, C.c_uint, C.POINTER(_vp)]),
+    "tomo_ctx_destroy": (_i, [_vp]),
+    "tomo_ctx_os_number": (_i, [_vp]),
+    "tomo_ctx_num_bins": (_i, [_vp]),
+    "tomo_ctx_newind_table": (_i, [_vp, C.POINTER(C.c_int64)]),
+    "tomo_ctx_subset_size": (_i, [_vp, _i]),
+    "tomo_ctx_angle_table": (_i, [_vp, _i, C.POINTER(AngleRecord), _i]),
+    "tomo_ctx_release_scratch": (_i, [_vp]),
+    "tomo_fp3d": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "tomo_bp3d": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "tomo_fp3d_residual": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "tomo_bp3d_fista": (_i, [_vp, _i, _vp, _vp, _vp, _f, _i, _vp]),
+    "tomo_bp3d_fista_momentum": (_i, [_vp, _i, _vp, _vp, _vp, _f, _f, _i, _vp]),
+    "tomo_bp3d_admm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _f, _i, _vp]),
+    "tomo_momentum": (_i, [_vp, _vp, _vp, _f, _sz, _vp]),
+    "tomo_admm_dual": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "tomo_axpby": (_i, [_f, _vp, _f, _vp, _sz, _vp]),
+    "tomo_scale": (_i, [_f, _vp, _vp, _sz, _vp]),
+    "tomo_clamp_min": (_i, [_vp, _f, _sz, _vp]),
+    "tomo_mul": (_i, [_vp, _vp, _sz, _vp]),
+    "tomo_recip_safe": (_i, [_vp, _vp, _sz, _vp]),
+    "tomo_fill": (_i, [_vp, _f, _sz, _vp]),
+    "tomo_norm2": (_i, [_vp, _sz, C.POINTER(_d), _vp]),
+    "tomo_dot": (_i, [_vp, _vp, _sz, C.POINTER(_d), _vp]),
+    "tomo_max": (_i, [_vp, _sz, C.POINTER(_f), _vp]),
+    "tomo_pwls_weights": (_i, [_vp, _vp, _sz, _vp]),
+    "tomo_pad_edge": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "tomo_crop_center": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "tomo_circ_mask": (_i, [_vp, _i, _i, _d, _vp]),
+    "tomo_permute3": (_i, [_vp, _vp, _i, _i, _i, C.c_int64, C.c_int64, C.c_int64, _vp]),
+    "tomo_pdtv": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _i, _i, _i, _i, _vp]),
+    "tomo_roftv": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp]),
+    "tomo_pdtv_scratch_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "tomo_roftv_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "tomo_release_scratch": (_i, [_i]),
+    "tomo_pdtv_iter_slab": (_i, [_i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i,
+                                 _f, _f, _f, _f, _i, _i, _i, _vp]),
+    "tomo_roftv_iter_slab": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
+    "tomo_set_variant": (_i, [C.c_char_p, _i]),
+}
+
+_lib = None
+
+
+class TomoRuntimeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library (once).  Raises ImportError with build instructions if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+                "Build it with `make -C tomobar_amd/csrc` or `__graft_entry__.build()`.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.tomo_abi_version() != 1:
+            raise ImportError("libtomo_mi355x.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int):
+    """Map a C-ABI status to the exception type the reference raises for the same condition."""
+    if rc == OK:
+        return
+    msg = lib().tomo_last_error().decode("utf-8", "replace")
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    if rc == E_NOMEM:
+        raise MemoryError(msg)
+    raise TomoRuntimeError(msg)

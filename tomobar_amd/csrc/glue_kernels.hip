@@ -1,0 +1,325 @@
+// Element-wise glue, reductions and pre/post kernels of the FISTA / ADMM loops (HBM-streaming, float4).
+// Compiled with -ffp-contract=off: every rounding below is the one the reference's separate CuPy
+// ufunc launches produce (methodsIR_CuPy.py:463-475,545-566); fmaf appears only where stated.
+#include "tomo_common.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+constexpr int EW_MAX_GRID = 256 * 8;  // 256 CUs x 8 blocks, grid-stride beyond
+
+inline int ew_grid(size_t n4)
+{
+    size_t g = (n4 + EW_BLOCK - 1) / EW_BLOCK;
+    if (g < 1) g = 1;
+    if (g > (size_t)EW_MAX_GRID) g = EW_MAX_GRID;
+    return (int)g;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- generic streaming kernels: up to 3 inputs, up to 2 outputs, functor works on scalars
+template <int NIN, int NOUT, typename F>
+__global__ __launch_bounds__(EW_BLOCK) void ew_vec4(const float *a, const float *b,
+                                                    const float *c, float *o0, float *o1,
+                                                    size_t n, F f)
+{
+    const size_t n4 = n >> 2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 va = reinterpret_cast<const float4 *>(a)[i];
+        float4 vb = NIN > 1 ? reinterpret_cast<const float4 *>(b)[i] : va;
+        float4 vc = NIN > 2 ? reinterpret_cast<const float4 *>(c)[i] : va;
+        float4 r0, r1;
+        f(va.x, vb.x, vc.x, r0.x, r1.x);
+        f(va.y, vb.y, vc.y, r0.y, r1.y);
+        f(va.z, vb.z, vc.z, r0.z, r1.z);
+        f(va.w, vb.w, vc.w, r0.w, r1.w);
+        reinterpret_cast<float4 *>(o0)[i] = r0;
+        if (NOUT > 1) reinterpret_cast<float4 *>(o1)[i] = r1;
+    }
+    // tail (n % 4) by the first few threads of block 0
+    const size_t tail0 = n4 << 2;
+    if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
+        size_t i = tail0 + threadIdx.x;
+        float r0, r1;
+        f(a[i], NIN > 1 ? b[i] : 0.0f, NIN > 2 ? c[i] : 0.0f, r0, r1);
+        o0[i] = r0;
+        if (NOUT > 1) o1[i] = r1;
+    }
+}
+
+template <int NIN, int NOUT, typename F>
+__global__ __launch_bounds__(EW_BLOCK) void ew_scalar(const float *a, const float *b, const float *c, float *o0,
+                                                      float *o1, size_t n, F f)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float r0, r1;
+        f(a[i], NIN > 1 ? b[i] : 0.0f, NIN > 2 ? c[i] : 0.0f, r0, r1);
+        o0[i] = r0;
+        if (NOUT > 1) o1[i] = r1;
+    }
+}
+
+template <int NIN, int NOUT, typename F>
+int ew_launch(const float *a, const float *b, const float *c, float *o0, float *o1, size_t n, void *stream, F f)
+{
+    if (n == 0) return TOMO_OK;
+    bool vec = aligned16(a) && aligned16(o0) && (NIN < 2 || aligned16(b)) && (NIN < 3 || aligned16(c)) &&
+               (NOUT < 2 || aligned16(o1));
+    if (vec)
+        ew_vec4<NIN, NOUT, F><<<ew_grid(n >> 2), EW_BLOCK, 0, as_stream(stream)>>>(a, b, c, o0, o1, n, f);
+    else
+        ew_scalar<NIN, NOUT, F><<<ew_grid(n), EW_BLOCK, 0, as_stream(stream)>>>(a, b, c, o0, o1, n, f);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
+struct MomentumF {  // X_t = X + beta*(X - X_old): mul then add, no fma (two CuPy ufuncs)
+    float beta;
+    __device__ void operator()(float x, float xo, float, float &r0, float &) const { r0 = x + beta * (x - xo); }
+};
+struct AdmmDualF {  // u = u + (z - x)
+    __device__ void operator()(float u, float z, float x, float &r0, float &) const { r0 = u + (z - x); }
+};
+struct AxpbyF {
+    float a, b;
+    __device__ void operator()(float x, float y, float, float &r0, float &) const { r0 = a * x + b * y; }
+};
+struct ScaleF {
+    float a;
+    __device__ void operator()(float x, float, float, float &r0, float &) const { r0 = a * x; }
+};
+struct ClampF {
+    float lo;
+    __device__ void operator()(float x, float, float, float &r0, float &) const { r0 = x < lo ? lo : x; }
+};
+struct MulF {
+    __device__ void operator()(float x, float y, float, float &r0, float &) const { r0 = x * y; }
+};
+struct RecipSafeF {  // 1/x with nan, +inf, -inf -> 1   (cp.nan_to_num(..., nan=1, posinf=1, neginf=1))
+    __device__ void operator()(float x, float, float, float &r0, float &) const
+    {
+        float r = 1.0f / x;
+        r0 = (isnan(r) || isinf(r)) ? 1.0f : r;
+    }
+};
+struct FillF {
+    float v;
+    __device__ void operator()(float, float, float, float &r0, float &) const { r0 = v; }
+};
+struct PwlsF {  // w = max(b, 1e-6) / wmax
+    float wmax;
+    __device__ void operator()(float b, float, float, float &r0, float &) const
+    {
+        float w = b < 1e-6f ? 1e-6f : b;
+        r0 = w / wmax;
+    }
+};
+
+// ---- reductions: per-block partials in double, finished on the host (the value is returned to the host anyway)
+enum { RED_SUMSQ = 0, RED_DOT = 1, RED_MAX = 2, RED_MAX_CLAMPED = 3 };
+
+template <int MODE>
+__global__ __launch_bounds__(EW_BLOCK) void reduce_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                          size_t n, double *partial)
+{
+    double acc = (MODE >= RED_MAX) ? -INFINITY : 0.0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = x[i];
+        if (MODE == RED_SUMSQ) acc += (double)v * (double)v;
+        else if (MODE == RED_DOT) acc += (double)v * (double)y[i];
+        else if (MODE == RED_MAX) acc = fmax(acc, (double)v);
+        else acc = fmax(acc, (double)(v < 1e-6f ? 1e-6f : v));
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_down(acc, off, 64);
+        acc = (MODE >= RED_MAX) ? fmax(acc, o) : acc + o;
+    }
+    __shared__ double wave_part[EW_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = wave_part[0];
+        for (int w = 1; w < EW_BLOCK / 64; ++w) r = (MODE >= RED_MAX) ? fmax(r, wave_part[w]) : r + wave_part[w];
+        partial[blockIdx.x] = r;
+    }
+}
+
+template <int MODE>
+int reduce_host(const float *x, const float *y, size_t n, double *out, void *stream)
+{
+    TOMO_REQUIRE(out != nullptr, "out is NULL");
+    if (n == 0) { *out = (MODE >= RED_MAX) ? -INFINITY : 0.0; return TOMO_OK; }
+    int dev = 0;
+    TOMO_HIP(hipGetDevice(&dev));
+    const int grid = ew_grid(n);
+    void *buf = nullptr;
+    int rc = tomo_arena_get(dev + 1024, (size_t)EW_MAX_GRID * sizeof(double), &buf);  // small dedicated arena
+    if (rc != TOMO_OK) return rc;
+    reduce_kernel<MODE><<<grid, EW_BLOCK, 0, as_stream(stream)>>>(x, y, n, (double *)buf);
+    TOMO_LAUNCH_CHECK();
+    std::vector<double> host(grid);
+    TOMO_HIP(hipMemcpyAsync(host.data(), buf, grid * sizeof(double), hipMemcpyDeviceToHost, as_stream(stream)));
+    TOMO_HIP(hipStreamSynchronize(as_stream(stream)));
+    double r = host[0];
+    for (int i = 1; i < grid; ++i) r = (MODE >= RED_MAX) ? (host[i] > r ? host[i] : r) : r + host[i];
+    *out = r;
+    return TOMO_OK;
+}
+
+// ---- pre/post
+__global__ void pad_edge_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int nu0, int pad)
+{
+    const int nu = nu0 + 2 * pad;
+    const size_t total = (size_t)rows * nu;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        size_t r = i / nu;
+        int u = (int)(i - r * nu) - pad;
+        u = u < 0 ? 0 : (u >= nu0 ? nu0 - 1 : u);
+        out[i] = in[r * nu0 + u];
+    }
+}
+
+__global__ void crop_kernel(const float *__restrict__ in, float *__restrict__ out, int nz, int n, int m, int a0)
+{
+    const size_t total = (size_t)nz * m * m;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        size_t z = i / ((size_t)m * m);
+        size_t rem = i - z * m * m;
+        int y = (int)(rem / m), x = (int)(rem - (size_t)y * m);
+        out[i] = in[(z * n + (y + a0)) * n + (x + a0)];
+    }
+}
+
+__global__ void mask_kernel(float *vol, int nz, int n, double limit)
+{
+    // dist computed as sqrt of an exact integer in double, as numpy does (suppTools.py:381-385)
+    const size_t total = (size_t)nz * n * n;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int h = n / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        size_t rem = i % ((size_t)n * n);
+        int y = (int)(rem / n), x = (int)(rem - (size_t)y * n);
+        double d = sqrt((double)((x - h) * (x - h) + (y - h) * (y - h)));
+        if (!(d <= limit)) vol[i] = vol[i] * 0.0f;  // data *= mask (keeps the sign of zero / NaN like the reference)
+    }
+}
+
+__global__ void permute3_kernel(const float *__restrict__ in, float *__restrict__ out, int d0, int d1, int d2,
+                                long long s0, long long s1, long long s2)
+{
+    const size_t total = (size_t)d0 * d1 * d2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        size_t a = i / ((size_t)d1 * d2);
+        size_t rem = i - a * d1 * d2;
+        size_t b = rem / d2, c = rem - b * d2;
+        out[i] = in[(long long)a * s0 + (long long)b * s1 + (long long)c * s2];
+    }
+}
+
+}  // namespace
+
+extern "C" int tomo_momentum(const float *x, const float *xold, float *xt, float beta, size_t count, void *stream)
+{
+    return ew_launch<2, 1>(x, xold, nullptr, xt, nullptr, count, stream, MomentumF{beta});
+}
+extern "C" int tomo_admm_dual(float *u, const float *z, const float *x, size_t count, void *stream)
+{
+    return ew_launch<3, 1>(u, z, x, u, nullptr, count, stream, AdmmDualF{});
+}
+extern "C" int tomo_axpby(float a, const float *x, float b, float *y, size_t count, void *stream)
+{
+    return ew_launch<2, 1>(x, y, nullptr, y, nullptr, count, stream, AxpbyF{a, b});
+}
+extern "C" int tomo_scale(float a, const float *x, float *y, size_t count, void *stream)
+{
+    return ew_launch<1, 1>(x, nullptr, nullptr, y, nullptr, count, stream, ScaleF{a});
+}
+extern "C" int tomo_clamp_min(float *x, float lo, size_t count, void *stream)
+{
+    return ew_launch<1, 1>(x, nullptr, nullptr, x, nullptr, count, stream, ClampF{lo});
+}
+extern "C" int tomo_mul(const float *x, float *y, size_t count, void *stream)
+{
+    return ew_launch<2, 1>(x, y, nullptr, y, nullptr, count, stream, MulF{});
+}
+extern "C" int tomo_recip_safe(const float *x, float *y, size_t count, void *stream)
+{
+    return ew_launch<1, 1>(x, nullptr, nullptr, y, nullptr, count, stream, RecipSafeF{});
+}
+extern "C" int tomo_fill(float *x, float value, size_t count, void *stream)
+{
+    return ew_launch<1, 1>(x, nullptr, nullptr, x, nullptr, count, stream, FillF{value});
+}
+
+extern "C" int tomo_norm2(const float *x, size_t count, double *out_host, void *stream)
+{
+    double s = 0.0;
+    int rc = reduce_host<RED_SUMSQ>(x, nullptr, count, &s, stream);
+    if (rc == TOMO_OK) *out_host = sqrt(s);
+    return rc;
+}
+extern "C" int tomo_dot(const float *x, const float *y, size_t count, double *out_host, void *stream)
+{
+    return reduce_host<RED_DOT>(x, y, count, out_host, stream);
+}
+extern "C" int tomo_max(const float *x, size_t count, float *out_host, void *stream)
+{
+    double m = 0.0;
+    int rc = reduce_host<RED_MAX>(x, nullptr, count, &m, stream);
+    if (rc == TOMO_OK) *out_host = (float)m;
+    return rc;
+}
+extern "C" int tomo_pwls_weights(const float *b, float *w, size_t count, void *stream)
+{
+    double m = 0.0;
+    int rc = reduce_host<RED_MAX_CLAMPED>(b, nullptr, count, &m, stream);
+    if (rc != TOMO_OK) return rc;
+    return ew_launch<1, 1>(b, nullptr, nullptr, w, nullptr, count, stream, PwlsF{(float)m});
+}
+
+extern "C" int tomo_pad_edge(const float *in, float *out, int rows, int nu0, int pad, void *stream)
+{
+    TOMO_REQUIRE(rows >= 0 && nu0 > 0 && pad >= 0, "bad padding arguments");
+    size_t total = (size_t)rows * (nu0 + 2 * pad);
+    if (total == 0) return TOMO_OK;
+    pad_edge_kernel<<<ew_grid(total), EW_BLOCK, 0, as_stream(stream)>>>(in, out, rows, nu0, pad);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
+extern "C" int tomo_crop_center(const float *in, float *out, int nz, int n, int m, void *stream)
+{
+    TOMO_REQUIRE(nz > 0 && n > 0 && m > 0 && m <= n, "bad crop arguments");
+    const int a0 = (n - m) / 2;
+    crop_kernel<<<ew_grid((size_t)nz * m * m), EW_BLOCK, 0, as_stream(stream)>>>(in, out, nz, n, m, a0);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
+extern "C" int tomo_circ_mask(float *vol, int nz, int n, double radius, void *stream)
+{
+    TOMO_REQUIRE(nz > 0 && n > 0, "bad mask arguments");
+    // suppTools.py:387-394, evaluated in double like the reference's Python floats
+    const double h = (double)(n / 2), r = radius;
+    const double limit = (r <= 1.0) ? h - fabs(h - h / r) : h + fabs(h - h / r);
+    mask_kernel<<<ew_grid((size_t)nz * n * n), EW_BLOCK, 0, as_stream(stream)>>>(vol, nz, n, limit);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
+extern "C" int tomo_permute3(const float *in, float *out, int d0, int d1, int d2, int64_t s0, int64_t s1,
+                             int64_t s2, void *stream)
+{
+    TOMO_REQUIRE(d0 > 0 && d1 > 0 && d2 > 0, "bad permute dims");
+    permute3_kernel<<<ew_grid((size_t)d0 * d1 * d2), EW_BLOCK, 0, as_stream(stream)>>>(in, out, d0, d1, d2, s0, s1, s2);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}

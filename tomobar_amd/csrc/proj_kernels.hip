@@ -1,0 +1,444 @@
+// Parallel-beam 3D projector pair for gfx950 with the FISTA / ADMM epilogues fused in.
+//
+// Model (fixed by the reference's geometry, supp/funcs.py:45-65, and by the ASTRA operators it calls at
+// astra_base.py:554,601; restated in oracle/tomo_oracle.c):
+//   BP  voxel-driven: vol[z,y,x] = sum_a lerp_u( sino[z,a,:], x_w cos + y_w sin - cor + nu/2 - 1/2 )
+//   FP  ray-driven Joseph: step along the dominant axis, 2-tap linear interpolation along the other in-plane
+//       axis, zero outside the volume, scaled by the ray length per step.
+// MI355X mapping:
+//   * BP variant 0 ("tiled"): a 256-thread workgroup owns a 64(x) x 8(y) x 16(z) voxel brick.  The lanes of a
+//     wave walk x, so the detector coordinate is affine along the wave.  For a batch of 8 angles the
+//     [angle][z-quad][u] window of the sinogram that the brick can touch is staged in LDS as float4 over z:
+//     one ds_read_b128 per tap serves four slices, interpolation index/weights are computed once per
+//     (voxel column, angle) and reused by all 16 slices.  Workgroups are numbered so that each XCD's L2 sees
+//     one z-batch of sinogram rows at a time.
+//   * BP variant 1 ("direct"): taps straight from global memory (L1/L2), 4 slices per thread.
+//   * FP: one lane per detector pixel, 4 slices per lane, sequential march (bit-identical to the oracle);
+//     x-stepping angles read an in-plane transposed copy of the volume so that the interpolation axis is
+//     always the contiguous one.
+//   * epilogues: plain / residual (FP) and plain / FISTA step / FISTA step+momentum / ADMM z-update (BP).
+// No MFMA: there is no dense contraction on this path.
+#include "tomo_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ shared pieces
+template <bool LERP8>
+__device__ __forceinline__ float lerp_w(float f, float fl)
+{
+    float w = f - fl;
+    if (LERP8) w = rintf(w * 256.0f) * (1.0f / 256.0f);
+    return w;
+}
+
+enum { EPI_PLAIN = 0, EPI_FISTA = 1, EPI_FISTA_MOM = 2, EPI_ADMM = 3 };
+
+struct BpArgs {
+    const float *sino;       // [nz][na][nu]
+    const tomo_angle_t *tab; // na records
+    int nz, n, nu, na;
+    float *vol;              // EPI_PLAIN: output volume
+    // fused epilogues
+    const float *xt;         // FISTA: X_t (in)         ADMM: x
+    float *xout;             // FISTA: X (out)          ADMM: z (in/out)
+    float *xt_out;           // FISTA_MOM: new X_t      ADMM: zu (out)
+    const float *xold;       // FISTA_MOM: X_old (==xout buffer)   ADMM: u
+    float s0, s1, s2, s3;    // FISTA: l_inv, beta ; ADMM: tau, rho, (1-alpha), alpha
+    int nonneg, relax_on;
+    int ntx, nty, nzb;       // tiled variant: tile counts
+};
+
+// No contraction here: these are the separate CuPy ufunc roundings of methodsIR_CuPy.py:463-475,545-557.
+template <int EPI>
+__device__ __forceinline__ void bp_epilogue(const BpArgs &a, size_t idx, float g)
+{
+    if (EPI == EPI_PLAIN) {
+        a.vol[idx] = g;
+    } else if (EPI == EPI_FISTA) {
+        float x = a.xt[idx] - a.s0 * g;
+        if (a.nonneg) x = x < 0.0f ? 0.0f : x;
+        a.xout[idx] = x;
+    } else if (EPI == EPI_FISTA_MOM) {
+        float x = a.xt[idx] - a.s0 * g;
+        if (a.nonneg) x = x < 0.0f ? 0.0f : x;
+        const float xo = a.xold[idx];
+        a.xout[idx] = x;
+        a.xt_out[idx] = x + a.s1 * (x - xo);
+    } else {
+        const float z0 = a.xout[idx], u = a.xold[idx];
+        const float ga = a.s1 * ((z0 - a.xt[idx]) + u);
+        float z = z0 - a.s0 * (g + ga);
+        if (a.nonneg) z = z < 0.0f ? 0.0f : z;
+        if (a.relax_on) z = a.s2 * z0 + a.s3 * z;
+        a.xout[idx] = z;
+        a.xt_out[idx] = z + u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ BP variant 1
+template <int EPI, bool LERP8>
+__global__ __launch_bounds__(256) void bp_direct_kernel(BpArgs a)
+{
+    constexpr int ZB = 4;
+    const int ix = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int iy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int z0 = blockIdx.z * ZB;
+    if (ix >= a.n || iy >= a.n) return;
+    const float half_n = 0.5f * (float)a.n - 0.5f, half_u = 0.5f * (float)a.nu - 0.5f;
+    const float xw = (float)ix - half_n, yw = (float)iy - half_n;
+    float acc[ZB] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const size_t zstride = (size_t)a.na * a.nu;
+    for (int k = 0; k < a.na; ++k) {
+        const tomo_angle_t t = a.tab[k];
+        const float off = half_u - t.cor;
+        const float f = fmaf(xw, t.cs, fmaf(yw, t.sn, off));
+        const float fl = floorf(f);
+        const float w = lerp_w<LERP8>(f, fl), omw = 1.0f - w;
+        const int i0 = (int)fl;
+        const bool ok0 = (i0 >= 0) && (i0 < a.nu), ok1 = (i0 + 1 >= 0) && (i0 + 1 < a.nu);
+        const float *row = a.sino + ((size_t)z0 * a.na + k) * a.nu;
+#pragma unroll
+        for (int zz = 0; zz < ZB; ++zz) {
+            const bool zok = z0 + zz < a.nz;
+            const float s0 = (ok0 && zok) ? row[zz * zstride + i0] : 0.0f;
+            const float s1 = (ok1 && zok) ? row[zz * zstride + i0 + 1] : 0.0f;
+            acc[zz] = fmaf(omw, s0, acc[zz]);
+            acc[zz] = fmaf(w, s1, acc[zz]);
+        }
+    }
+#pragma unroll
+    for (int zz = 0; zz < ZB; ++zz)
+        if (z0 + zz < a.nz) bp_epilogue<EPI>(a, ((size_t)(z0 + zz) * a.n + iy) * a.n + ix, acc[zz]);
+}
+
+// ------------------------------------------------------------------------------------------ BP variant 0
+constexpr int BP_TX = 64, BP_TY = 8, BP_RY = 2, BP_ZQ = 4, BP_AB = 8, BP_PITCH = 72;
+
+template <int EPI, bool LERP8>
+__global__ __launch_bounds__(256) void bp_tiled_kernel(BpArgs a)
+{
+    __shared__ float4 tile[BP_AB][BP_ZQ][BP_PITCH];  // 36 KiB
+    __shared__ int umin_s[BP_AB];
+
+    // XCD-aware numbering: workgroup b lands on XCD b%8; give each XCD its own z-batch stream
+    const int ntiles = a.ntx * a.nty;
+    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+    const int zb = (q / ntiles) * 8 + xcd;
+    if (zb >= a.nzb) return;  // uniform for the workgroup
+    const int tid = q % ntiles;
+    const int tx0 = (tid % a.ntx) * BP_TX, ty0 = (tid / a.ntx) * BP_TY;
+    const int z0 = zb * (4 * BP_ZQ);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ix = tx0 + lane;
+    const float half_n = 0.5f * (float)a.n - 0.5f, half_u = 0.5f * (float)a.nu - 0.5f;
+    const float xw = (float)ix - half_n;
+    float yw[BP_RY];
+#pragma unroll
+    for (int r = 0; r < BP_RY; ++r) yw[r] = (float)(ty0 + wave * BP_RY + r) - half_n;
+
+    float acc[BP_RY][4 * BP_ZQ];
+#pragma unroll
+    for (int r = 0; r < BP_RY; ++r)
+#pragma unroll
+        for (int j = 0; j < 4 * BP_ZQ; ++j) acc[r][j] = 0.0f;
+
+    const size_t zstride = (size_t)a.na * a.nu;
+    for (int a0 = 0; a0 < a.na; a0 += BP_AB) {
+        const int nb = min(BP_AB, a.na - a0);
+        __syncthreads();  // previous batch fully consumed
+        if ((int)threadIdx.x < nb) {
+            // detector window of the brick: the coordinate is monotone in x and in y, so the four corners bound it
+            const tomo_angle_t t = a.tab[a0 + threadIdx.x];
+            const float off = half_u - t.cor;
+            const float x0 = (float)tx0 - half_n, x1 = (float)(tx0 + BP_TX - 1) - half_n;
+            const float y0 = (float)ty0 - half_n, y1 = (float)(ty0 + BP_TY - 1) - half_n;
+            const float f00 = fmaf(x0, t.cs, fmaf(y0, t.sn, off)), f10 = fmaf(x1, t.cs, fmaf(y0, t.sn, off));
+            const float f01 = fmaf(x0, t.cs, fmaf(y1, t.sn, off)), f11 = fmaf(x1, t.cs, fmaf(y1, t.sn, off));
+            umin_s[threadIdx.x] = (int)floorf(fminf(fminf(f00, f10), fminf(f01, f11)));
+        }
+        __syncthreads();
+        // stage [angle][z-quad][u] as float4 over z: four coalesced row reads, one 16-byte LDS write
+        for (int item = threadIdx.x; item < nb * BP_ZQ * BP_PITCH; item += 256) {
+            const int j = item % BP_PITCH;
+            const int zq = (item / BP_PITCH) % BP_ZQ;
+            const int aa = item / (BP_PITCH * BP_ZQ);
+            const int u = umin_s[aa] + j;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (u >= 0 && u < a.nu) {
+                const int z = z0 + zq * 4;
+                const float *p = a.sino + ((size_t)z * a.na + (a0 + aa)) * a.nu + u;
+                if (z + 0 < a.nz) v.x = p[0];
+                if (z + 1 < a.nz) v.y = p[zstride];
+                if (z + 2 < a.nz) v.z = p[2 * zstride];
+                if (z + 3 < a.nz) v.w = p[3 * zstride];
+            }
+            tile[aa][zq][j] = v;
+        }
+        __syncthreads();
+        for (int aa = 0; aa < nb; ++aa) {
+            const tomo_angle_t t = a.tab[a0 + aa];
+            const float off = half_u - t.cor;
+            const int um = umin_s[aa];
+#pragma unroll
+            for (int r = 0; r < BP_RY; ++r) {
+                const float f = fmaf(xw, t.cs, fmaf(yw[r], t.sn, off));
+                const float fl = floorf(f);
+                const float w = lerp_w<LERP8>(f, fl), omw = 1.0f - w;
+                const int idx = (int)fl - um;
+#pragma unroll
+                for (int zq = 0; zq < BP_ZQ; ++zq) {
+                    const float4 s0 = tile[aa][zq][idx];
+                    const float4 s1 = tile[aa][zq][idx + 1];
+                    float *c = &acc[r][zq * 4];
+                    c[0] = fmaf(omw, s0.x, c[0]); c[0] = fmaf(w, s1.x, c[0]);
+                    c[1] = fmaf(omw, s0.y, c[1]); c[1] = fmaf(w, s1.y, c[1]);
+                    c[2] = fmaf(omw, s0.z, c[2]); c[2] = fmaf(w, s1.z, c[2]);
+                    c[3] = fmaf(omw, s0.w, c[3]); c[3] = fmaf(w, s1.w, c[3]);
+                }
+            }
+        }
+    }
+    if (ix < a.n) {
+#pragma unroll
+        for (int r = 0; r < BP_RY; ++r) {
+            const int iy = ty0 + wave * BP_RY + r;
+            if (iy < a.n) {
+#pragma unroll
+                for (int j = 0; j < 4 * BP_ZQ; ++j)
+                    if (z0 + j < a.nz) bp_epilogue<EPI>(a, ((size_t)(z0 + j) * a.n + iy) * a.n + ix, acc[r][j]);
+            }
+        }
+    }
+}
+
+template <int EPI>
+int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
+{
+    if (g_variant_bp == 1) {
+        dim3 grid(ceil_div(a.n, 64), ceil_div(a.n, 4), ceil_div(a.nz, 4));
+        if (lerp8) bp_direct_kernel<EPI, true><<<grid, 256, 0, st>>>(a);
+        else bp_direct_kernel<EPI, false><<<grid, 256, 0, st>>>(a);
+    } else {
+        a.ntx = ceil_div(a.n, BP_TX);
+        a.nty = ceil_div(a.n, BP_TY);
+        a.nzb = ceil_div(a.nz, 4 * BP_ZQ);
+        const long blocks = 8L * ceil_div(a.nzb, 8) * a.ntx * a.nty;
+        if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one BP launch");
+        if (lerp8) bp_tiled_kernel<EPI, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+        else bp_tiled_kernel<EPI, false><<<(unsigned)blocks, 256, 0, st>>>(a);
+    }
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
+// ------------------------------------------------------------------------------------------ FP
+struct FpArgs {
+    const float *vol;        // [nz][n][n]   (y rows, x contiguous)
+    const float *volT;       // [nz][n][n]   (x rows, y contiguous) -- may be null when no angle steps along x
+    const tomo_angle_t *tab;
+    int nz, n, nu, na, na_full;
+    float *out;              // [nz][na][nu]
+    const float *b;          // residual epilogue: full sinogram [nz][na_full][nu] (null = plain FP)
+    const float *w;          // PWLS weights, full sinogram (may be null)
+    int fidelity;
+    int gathered;            // bit0: b is the gathered subset, bit1: w is
+};
+
+__global__ __launch_bounds__(256) void transpose_inplane_kernel(const float *__restrict__ in, float *__restrict__ out, int n)
+{
+    __shared__ float t[32][33];
+    const size_t zoff = (size_t)blockIdx.z * n * n;
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ly; r < 32; r += 8) {
+        const int x = bx + lx, y = by + r;
+        t[r][lx] = (x < n && y < n) ? in[zoff + (size_t)y * n + x] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ly; r < 32; r += 8) {
+        const int y = by + lx, x = bx + r;
+        if (x < n && y < n) out[zoff + (size_t)x * n + y] = t[lx][r];
+    }
+}
+
+template <bool LERP8, bool RESID>
+__global__ __launch_bounds__(256) void fp_march_kernel(FpArgs a)
+{
+    constexpr int ZB = 4;
+    const int iu = blockIdx.x * 256 + threadIdx.x;
+    const int k_a = blockIdx.y;
+    const int z0 = blockIdx.z * ZB;
+    if (iu >= a.nu) return;
+    const tomo_angle_t t = a.tab[k_a];
+    const float half_n = 0.5f * (float)a.n - 0.5f, half_u = 0.5f * (float)a.nu - 0.5f;
+    const float s = ((float)iu - half_u) + t.cor;
+    const float offset = fmaf(s, t.inv, half_n);
+    const float *src = t.dirx ? a.volT : a.vol;  // interpolation axis contiguous in either case
+    const size_t zstride = (size_t)a.n * a.n;
+    const int n = a.n;
+    float acc[ZB] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float *base = src + (size_t)z0 * zstride;
+    bool zok[ZB];
+#pragma unroll
+    for (int zz = 0; zz < ZB; ++zz) zok[zz] = z0 + zz < a.nz;
+#pragma unroll 2
+    for (int k = 0; k < n; ++k) {
+        const float kw = (float)k - half_n;
+        const float f = fmaf(kw, t.slope, offset);
+        const float fl = floorf(f);
+        const float w = lerp_w<LERP8>(f, fl), omw = 1.0f - w;
+        const int i0 = (int)fl;
+        const bool ok0 = (i0 >= 0) && (i0 < n), ok1 = (i0 + 1 >= 0) && (i0 + 1 < n);
+        const float *row = base + (size_t)k * n;
+#pragma unroll
+        for (int zz = 0; zz < ZB; ++zz) {
+            const float v0 = (ok0 && zok[zz]) ? row[zz * zstride + i0] : 0.0f;
+            const float v1 = (ok1 && zok[zz]) ? row[zz * zstride + i0 + 1] : 0.0f;
+            acc[zz] = fmaf(omw, v0, acc[zz]);
+            acc[zz] = fmaf(w, v1, acc[zz]);
+        }
+    }
+#pragma unroll
+    for (int zz = 0; zz < ZB; ++zz) {
+        if (!zok[zz]) continue;
+        const int z = z0 + zz;
+        float val = acc[zz] * t.scale;
+        if (RESID) {
+            const size_t gi = ((size_t)z * a.na + k_a) * a.nu + iu;          // gathered layout
+            const size_t fi = ((size_t)z * a.na_full + t.src) * a.nu + iu;   // full-sinogram layout
+            const float bv = a.b[(a.gathered & TOMO_GATHERED_B) ? gi : fi];
+            if (a.fidelity == TOMO_FID_KL || a.fidelity == TOMO_FID_RATIO) {
+                const float ax = val < 1e-8f ? 1e-8f : val;
+                const float q = bv / ax;
+                val = (a.fidelity == TOMO_FID_KL) ? 1.0f - q : q;
+            } else {
+                val = val - bv;
+                if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
+            }
+        }
+        a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
+    }
+}
+
+int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const float *w, int gathered, int fidelity,
+           float *out, void *stream)
+{
+    TOMO_REQUIRE(ctx != nullptr, "ctx is NULL");
+    TOMO_REQUIRE(vol != nullptr && out != nullptr, "NULL data pointer");
+    TOMO_REQUIRE(subset < ctx->os, "subset %d out of range (OS_number %d)", subset, ctx->os);
+    const tomo_subset &s = (subset < 0 || ctx->os == 1) ? ctx->subsets[0] : ctx->subsets[1 + subset];
+    if (s.size == 0) return TOMO_OK;
+    TOMO_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = as_stream(stream);
+    FpArgs a;
+    a.vol = vol;
+    a.volT = nullptr;
+    if (s.n_dirx > 0) {
+        const size_t need = (size_t)ctx->nz * ctx->n * ctx->n * sizeof(float);
+        if (ctx->scratch_bytes < need) {
+            if (ctx->scratch) { TOMO_HIP(hipDeviceSynchronize()); TOMO_HIP(hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+            TOMO_HIP(hipMalloc(&ctx->scratch, need));
+            ctx->scratch_bytes = need;
+        }
+        dim3 tg(ceil_div(ctx->n, 32), ceil_div(ctx->n, 32), ctx->nz);
+        transpose_inplane_kernel<<<tg, 256, 0, st>>>(vol, (float *)ctx->scratch, ctx->n);
+        TOMO_LAUNCH_CHECK();
+        a.volT = (const float *)ctx->scratch;
+    }
+    a.tab = ctx->dev_table + s.table_offset;
+    a.nz = ctx->nz; a.n = ctx->n; a.nu = ctx->nu; a.na = s.size; a.na_full = ctx->na;
+    a.out = out; a.b = b; a.w = w; a.fidelity = fidelity; a.gathered = gathered;
+    dim3 grid(ceil_div(ctx->nu, 256), s.size, ceil_div(ctx->nz, 4));
+    const bool l8 = (ctx->flags & TOMO_FLAG_LERP8) != 0;
+    if (b) {
+        if (l8) fp_march_kernel<true, true><<<grid, 256, 0, st>>>(a);
+        else fp_march_kernel<false, true><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (l8) fp_march_kernel<true, false><<<grid, 256, 0, st>>>(a);
+        else fp_march_kernel<false, false><<<grid, 256, 0, st>>>(a);
+    }
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
+int bp_prepare(tomo_ctx *ctx, int subset, const float *sino, BpArgs &a)
+{
+    TOMO_REQUIRE(ctx != nullptr, "ctx is NULL");
+    TOMO_REQUIRE(subset < ctx->os, "subset %d out of range (OS_number %d)", subset, ctx->os);
+    const tomo_subset &s = (subset < 0 || ctx->os == 1) ? ctx->subsets[0] : ctx->subsets[1 + subset];
+    TOMO_REQUIRE(sino != nullptr || s.size == 0, "NULL sinogram pointer");
+    TOMO_HIP(hipSetDevice(ctx->device));
+    a = BpArgs();
+    a.sino = sino;
+    a.tab = ctx->dev_table + s.table_offset;
+    a.nz = ctx->nz; a.n = ctx->n; a.nu = ctx->nu; a.na = s.size;
+    return TOMO_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C-ABI
+extern "C" int tomo_fp3d(tomo_ctx *ctx, int subset, const float *vol_dev, float *sino_dev, void *stream)
+{
+    return fp_run(ctx, subset, vol_dev, nullptr, nullptr, 0, TOMO_FID_LS, sino_dev, stream);
+}
+
+extern "C" int tomo_fp3d_residual(tomo_ctx *ctx, int subset, const float *vol_dev, const float *b_full_dev,
+                                  const float *w_full_dev, int gathered, int fidelity, float *res_dev, void *stream)
+{
+    TOMO_REQUIRE(b_full_dev != nullptr, "projection data pointer is NULL");
+    TOMO_REQUIRE(fidelity == TOMO_FID_LS || fidelity == TOMO_FID_PWLS || fidelity == TOMO_FID_KL ||
+                     fidelity == TOMO_FID_RATIO,
+                 "data_fidelity should be LS, PWLS or KL");
+    TOMO_REQUIRE(fidelity != TOMO_FID_PWLS || w_full_dev != nullptr, "PWLS needs the weights");
+    return fp_run(ctx, subset, vol_dev, b_full_dev, fidelity == TOMO_FID_PWLS ? w_full_dev : nullptr, gathered,
+                  fidelity, res_dev, stream);
+}
+
+extern "C" int tomo_bp3d(tomo_ctx *ctx, int subset, const float *sino_dev, float *vol_dev, void *stream)
+{
+    BpArgs a;
+    int rc = bp_prepare(ctx, subset, sino_dev, a);
+    if (rc != TOMO_OK) return rc;
+    TOMO_REQUIRE(vol_dev != nullptr, "NULL volume pointer");
+    a.vol = vol_dev;
+    return bp_launch<EPI_PLAIN>(a, (ctx->flags & TOMO_FLAG_LERP8) != 0, as_stream(stream));
+}
+
+extern "C" int tomo_bp3d_fista(tomo_ctx *ctx, int subset, const float *res_dev, const float *xt_dev,
+                               float *xout_dev, float l_inv, int nonneg, void *stream)
+{
+    BpArgs a;
+    int rc = bp_prepare(ctx, subset, res_dev, a);
+    if (rc != TOMO_OK) return rc;
+    TOMO_REQUIRE(xt_dev && xout_dev, "NULL volume pointer");
+    a.xt = xt_dev; a.xout = xout_dev; a.s0 = l_inv; a.nonneg = nonneg;
+    return bp_launch<EPI_FISTA>(a, (ctx->flags & TOMO_FLAG_LERP8) != 0, as_stream(stream));
+}
+
+extern "C" int tomo_bp3d_fista_momentum(tomo_ctx *ctx, int subset, const float *res_dev, float *xt_dev,
+                                        float *xold_x_dev, float l_inv, float beta, int nonneg, void *stream)
+{
+    BpArgs a;
+    int rc = bp_prepare(ctx, subset, res_dev, a);
+    if (rc != TOMO_OK) return rc;
+    TOMO_REQUIRE(xt_dev && xold_x_dev, "NULL volume pointer");
+    a.xt = xt_dev; a.xt_out = xt_dev; a.xold = xold_x_dev; a.xout = xold_x_dev;
+    a.s0 = l_inv; a.s1 = beta; a.nonneg = nonneg;
+    return bp_launch<EPI_FISTA_MOM>(a, (ctx->flags & TOMO_FLAG_LERP8) != 0, as_stream(stream));
+}
+
+extern "C" int tomo_bp3d_admm(tomo_ctx *ctx, int subset, const float *res_dev, float *z_dev, const float *x_dev,
+                              const float *u_dev, float *zu_out_dev, float tau, float rho, int relax_on,
+                              float one_minus_alpha, float alpha, int nonneg, void *stream)
+{
+    BpArgs a;
+    int rc = bp_prepare(ctx, subset, res_dev, a);
+    if (rc != TOMO_OK) return rc;
+    TOMO_REQUIRE(z_dev && x_dev && u_dev && zu_out_dev, "NULL volume pointer");
+    a.xt = x_dev; a.xout = z_dev; a.xt_out = zu_out_dev; a.xold = u_dev;
+    a.s0 = tau; a.s1 = rho; a.s2 = one_minus_alpha; a.s3 = alpha;
+    a.nonneg = nonneg; a.relax_on = relax_on;
+    return bp_launch<EPI_ADMM>(a, (ctx->flags & TOMO_FLAG_LERP8) != 0, as_stream(stream));
+}

@@ -1,0 +1,238 @@
+// Context, geometry tables, error reporting and scratch arenas of libtomo_mi355x.so.
+#include "tomo_common.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+
+static thread_local char g_err[512] = "";
+
+int tomo_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int g_variant_bp = 0, g_variant_fp = 0, g_variant_pdtv = 0, g_variant_roftv = 0;
+
+extern "C" int tomo_abi_version(void) { return TOMO_ABI_VERSION; }
+extern "C" const char *tomo_last_error(void) { return g_err; }
+
+extern "C" int tomo_device_count(int *count)
+{
+    TOMO_REQUIRE(count != nullptr, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        *count = 0;
+        return tomo_fail(TOMO_E_NODEVICE, "no HIP device visible (%s); libtomo_mi355x has no CPU fallback",
+                         e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    *count = n;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_set_variant(const char *kernel, int variant)
+{
+    TOMO_REQUIRE(kernel != nullptr, "kernel name is NULL");
+    std::string k(kernel);
+    if (k == "bp") g_variant_bp = variant;
+    else if (k == "fp") g_variant_fp = variant;
+    else if (k == "pdtv") g_variant_pdtv = variant;
+    else if (k == "roftv") g_variant_roftv = variant;
+    else return tomo_fail(TOMO_E_INVALID, "unknown kernel '%s'", kernel);
+    return TOMO_OK;
+}
+
+// ---- per-angle record: rays (sin,-cos,0), u = (cos,sin,0), detector centre cor*u (supp/funcs.py:45-65)
+static tomo_angle_t make_angle(double theta, double cor, int src)
+{
+    tomo_angle_t t;
+    const double c = std::cos(theta), s = std::sin(theta);
+    t.cs = (float)c;
+    t.sn = (float)s;
+    t.cor = (float)cor;
+    t.dirx = std::fabs(s) >= std::fabs(c) ? 1 : 0;
+    if (t.dirx) {
+        t.slope = (float)(-c / s);
+        t.inv = (float)(1.0 / s);
+        t.scale = (float)(1.0 / std::fabs(s));
+    } else {
+        t.slope = (float)(-s / c);
+        t.inv = (float)(1.0 / c);
+        t.scale = (float)(1.0 / std::fabs(c));
+    }
+    t.src = src;
+    return t;
+}
+
+extern "C" int tomo_ctx_create(int device, int nz, int n, int nu, int na, const double *angles_host,
+                               const double *cor_host, int cor_stride, int os_number, unsigned flags,
+                               tomo_ctx **out)
+{
+    TOMO_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    TOMO_REQUIRE(nu > 0, "The size of the horizontal detector cannot be negative or zero");
+    TOMO_REQUIRE(nz > 0, "The size of the vertical detector cannot be negative or zero");
+    TOMO_REQUIRE(n > 0, "The size of the reconstruction object cannot be zero");
+    TOMO_REQUIRE(na > 0 && angles_host != nullptr, "The length of angles array cannot be zero");
+    TOMO_REQUIRE(os_number > 0, "The number of ordered subsets cannot be negative or zero");
+    TOMO_REQUIRE(cor_host != nullptr && cor_stride >= 0 && cor_stride <= 2, "bad centre-of-rotation argument");
+    TOMO_REQUIRE(device >= 0, "The GPU device index must be >= 0");
+    if (cor_stride == 2)
+        for (int a = 0; a < na; ++a)
+            TOMO_REQUIRE(cor_host[2 * a + 1] == 0.0,
+                         "a vertical centre-of-rotation component is not supported (angle %d)", a);
+    int ndev = 0;
+    int rc = tomo_device_count(&ndev);
+    if (rc != TOMO_OK) return rc;
+    TOMO_REQUIRE(device < ndev, "device index %d out of range (%d devices)", device, ndev);
+    TOMO_HIP(hipSetDevice(device));
+
+    tomo_ctx *ctx = new (std::nothrow) tomo_ctx();
+    if (!ctx) return tomo_fail(TOMO_E_NOMEM, "out of host memory");
+    ctx->device = device;
+    ctx->nz = nz; ctx->n = n; ctx->nu = nu; ctx->na = na;
+    ctx->os = os_number;
+    ctx->flags = flags;
+    ctx->bins = (int)std::ceil((double)na / (double)os_number);
+
+    auto cor_of = [&](int a) { return cor_stride == 0 ? cor_host[0] : cor_host[(size_t)a * cor_stride]; };
+    auto push_subset = [&](const std::vector<int64_t> &idx) {
+        tomo_subset s;
+        s.size = (int)idx.size();
+        s.table_offset = ctx->host_table.size();
+        for (int64_t a : idx) {
+            ctx->host_table.push_back(make_angle(angles_host[a], cor_of((int)a), (int)a));
+            s.n_dirx += ctx->host_table.back().dirx;
+        }
+        ctx->subsets.push_back(s);
+    };
+    std::vector<int64_t> all(na);
+    for (int a = 0; a < na; ++a) all[a] = a;
+    push_subset(all);
+    // interleaved subsets s, s+OS, ... (astra_base.py:195-209); tail entries stay 0
+    ctx->newind.assign((size_t)os_number * ctx->bins, 0);
+    for (int s = 0; s < os_number; ++s)
+        for (int k = 0; k < ctx->bins; ++k) {
+            int64_t a = (int64_t)s + (int64_t)k * os_number;
+            if (a < na) ctx->newind[(size_t)s * ctx->bins + k] = a;
+        }
+    if (os_number > 1) {
+        for (int s = 0; s < os_number; ++s) {
+            std::vector<int64_t> idx(ctx->newind.begin() + (size_t)s * ctx->bins,
+                                     ctx->newind.begin() + (size_t)(s + 1) * ctx->bins);
+            // consumers drop ONE trailing element when it is 0 (methodsIR_CuPy.py:454-456, astra_base.py:291-293)
+            if (idx[ctx->bins - 1] == 0) idx.pop_back();
+            push_subset(idx);
+        }
+    }
+    size_t bytes = ctx->host_table.size() * sizeof(tomo_angle_t);
+    hipError_t e = hipMalloc((void **)&ctx->dev_table, bytes > 0 ? bytes : sizeof(tomo_angle_t));
+    if (e == hipSuccess && bytes)
+        e = hipMemcpy(ctx->dev_table, ctx->host_table.data(), bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        delete ctx;
+        return tomo_fail(TOMO_E_RUNTIME, "angle table upload failed: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_ctx_destroy(tomo_ctx *ctx)
+{
+    if (!ctx) return TOMO_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->dev_table) (void)hipFree(ctx->dev_table);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    delete ctx;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_ctx_release_scratch(tomo_ctx *ctx)
+{
+    TOMO_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (ctx->scratch) {
+        TOMO_HIP(hipSetDevice(ctx->device));
+        TOMO_HIP(hipDeviceSynchronize());
+        TOMO_HIP(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    return TOMO_OK;
+}
+
+extern "C" int tomo_ctx_os_number(const tomo_ctx *ctx) { return ctx ? ctx->os : -1; }
+extern "C" int tomo_ctx_num_bins(const tomo_ctx *ctx) { return ctx ? ctx->bins : -1; }
+
+extern "C" int tomo_ctx_newind_table(const tomo_ctx *ctx, int64_t *out_host)
+{
+    TOMO_REQUIRE(ctx != nullptr && out_host != nullptr, "NULL argument");
+    std::memcpy(out_host, ctx->newind.data(), ctx->newind.size() * sizeof(int64_t));
+    return TOMO_OK;
+}
+
+static const tomo_subset *find_subset(const tomo_ctx *ctx, int subset)
+{
+    if (!ctx) return nullptr;
+    if (subset < 0 || ctx->os == 1) return &ctx->subsets[0];
+    if (subset >= ctx->os) return nullptr;
+    return &ctx->subsets[1 + subset];
+}
+
+extern "C" int tomo_ctx_subset_size(const tomo_ctx *ctx, int subset)
+{
+    const tomo_subset *s = find_subset(ctx, subset);
+    return s ? s->size : -1;
+}
+
+extern "C" int tomo_ctx_angle_table(const tomo_ctx *ctx, int subset, tomo_angle_t *out_host, int capacity)
+{
+    const tomo_subset *s = find_subset(ctx, subset);
+    TOMO_REQUIRE(s != nullptr && out_host != nullptr, "bad subset %d", subset);
+    TOMO_REQUIRE(capacity >= s->size, "capacity %d < subset size %d", capacity, s->size);
+    std::memcpy(out_host, ctx->host_table.data() + s->table_offset, (size_t)s->size * sizeof(tomo_angle_t));
+    return TOMO_OK;
+}
+
+// ---- per-device grow-only arena for the TV drivers
+struct arena_t { void *ptr = nullptr; size_t bytes = 0; };
+static std::mutex g_arena_mu;
+static std::map<int, arena_t> g_arenas;
+
+int tomo_arena_get(int device, size_t bytes, void **out)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    arena_t &a = g_arenas[device];
+    if (a.bytes < bytes) {
+        if (a.ptr) {
+            TOMO_HIP(hipDeviceSynchronize());
+            TOMO_HIP(hipFree(a.ptr));
+            a.ptr = nullptr;
+            a.bytes = 0;
+        }
+        TOMO_HIP(hipMalloc(&a.ptr, bytes));
+        a.bytes = bytes;
+    }
+    *out = a.ptr;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_release_scratch(int device)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    auto it = g_arenas.find(device);
+    if (it != g_arenas.end() && it->second.ptr) {
+        TOMO_HIP(hipSetDevice(device));
+        TOMO_HIP(hipDeviceSynchronize());
+        TOMO_HIP(hipFree(it->second.ptr));
+        g_arenas.erase(it);
+    }
+    return TOMO_OK;
+}

@@ -1,0 +1,64 @@
+// Internal declarations shared by the translation units of libtomo_mi355x.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "tomo_mi355x.h"
+
+int tomo_fail(int code, const char *fmt, ...);
+
+#define TOMO_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return tomo_fail(e_ == hipErrorOutOfMemory ? TOMO_E_NOMEM : TOMO_E_RUNTIME,          \
+                             "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,   \
+                             __LINE__);                                                         \
+    } while (0)
+
+#define TOMO_LAUNCH_CHECK()                                                                     \
+    do {                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ != hipSuccess)                                                                   \
+            return tomo_fail(TOMO_E_RUNTIME, "kernel launch failed: %s (%s:%d)",                \
+                             hipGetErrorString(e_), __FILE__, __LINE__);                        \
+    } while (0)
+
+#define TOMO_REQUIRE(cond, ...)                                                                 \
+    do {                                                                                        \
+        if (!(cond)) return tomo_fail(TOMO_E_INVALID, __VA_ARGS__);                              \
+    } while (0)
+
+struct tomo_subset {
+    int size = 0;             // number of angles
+    size_t table_offset = 0;  // element offset into the device angle table
+    int n_dirx = 0;           // how many angles step along x (FP)
+};
+
+struct tomo_ctx {
+    int device = 0;
+    int nz = 0, n = 0, nu = 0, na = 0;
+    int os = 1, bins = 0;
+    unsigned flags = 0;
+    std::vector<int64_t> newind;              // [os][bins]
+    std::vector<tomo_angle_t> host_table;     // full set followed by every subset
+    std::vector<tomo_subset> subsets;         // index 0 = full set, 1 + s = subset s
+    tomo_angle_t *dev_table = nullptr;
+    void *scratch = nullptr;                  // grow-only (FP: in-plane transposed volume)
+    size_t scratch_bytes = 0;
+};
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// grow-only per-device arena used by the TV drivers (tomo_release_scratch frees it)
+int tomo_arena_get(int device, size_t bytes, void **out);
+
+// kernel-variant switches (tomo_set_variant)
+extern int g_variant_bp, g_variant_fp, g_variant_pdtv, g_variant_roftv;
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

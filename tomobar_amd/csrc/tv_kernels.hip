@@ -1,0 +1,528 @@
+// TV proximal operators for gfx950: Chambolle-Pock primal-dual TV (PD_TV) and explicit ROF TV.
+//
+// What is computed is fixed by the reference kernels
+//   tomobar/cuda_kernels/primal_dual_for_total_variation.cu:125-261 (3D), :360-452 (2D)
+//   tomobar/cuda_kernels/rudin_osher_fatemi_total_variation.cu:66-137 (2D), :156-238 (3D)
+// How it is computed here is MI355X-first:
+//   * PD_TV variant 0 ("zmarch"): every 64-lane wave is autonomous.  A lane owns RY consecutive rows of one
+//     x column and marches along z.  +-y neighbours are other registers of the same lane, +-x neighbours come
+//     from wave shuffles, the z-1 dual is carried in registers from the previous step, so each U / P / Input
+//     value is read from HBM once per iteration (plus a one-row / one-lane halo served by L2) and no LDS or
+//     barrier is used.  Lane 0 of every wave is an x-halo lane (63 outputs per wave).
+//   * variant 1 ("pervoxel"): one thread per voxel, neighbours' duals recomputed from global memory; kept as
+//     an independent implementation for A/B checks.
+//   * ROF_TV: divergence and update kernels fused: the D fields never reach HBM (12 B/voxel/iteration).
+// All arithmetic is float32 with the rounding sequence of oracle/tomo_oracle.c (explicit fmaf, -ffp-contract=off).
+#include "tomo_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ helpers
+template <typename T> struct DualIO;
+template <> struct DualIO<float> {
+    static __device__ __forceinline__ float ld(const float *p, size_t i) { return p[i]; }
+    static __device__ __forceinline__ void st(float *p, size_t i, float v) { p[i] = v; }
+    static __device__ __forceinline__ float rt(float v) { return v; }
+};
+template <> struct DualIO<__half> {
+    static __device__ __forceinline__ float ld(const __half *p, size_t i) { return __half2float(p[i]); }
+    static __device__ __forceinline__ void st(__half *p, size_t i, float v) { p[i] = __float2half_rn(v); }
+    static __device__ __forceinline__ float rt(float v) { return __half2float(__float2half_rn(v)); }
+};
+
+// dual ascent + projection onto the unit ball (isotropic) / unit cube (anisotropic)
+template <int ND, bool ANISO>
+__device__ __forceinline__ void pd_dual(float (&p)[3], const float (&g)[3], float sigma)
+{
+#pragma unroll
+    for (int c = 0; c < ND; ++c) p[c] = fmaf(sigma, g[c], p[c]);
+    if (!ANISO) {
+        float nrm = p[0] * p[0];
+#pragma unroll
+        for (int c = 1; c < ND; ++c) nrm = fmaf(p[c], p[c], nrm);
+        if (nrm > 1.0f) {
+            float r = 1.0f / sqrtf(nrm);
+#pragma unroll
+            for (int c = 0; c < ND; ++c) p[c] *= r;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < ND; ++c) {
+            float v = fabsf(p[c]);
+            v = v < 1.0f ? 1.0f : v;
+            p[c] /= v;
+        }
+    }
+}
+
+__device__ __forceinline__ float pd_primal(float u_in, float input, float div, float tau, float lt, float theta,
+                                           bool nonneg)
+{
+    float u = (nonneg && u_in < 0.0f) ? 0.0f : u_in;
+    float t = fmaf(-tau, div, u);
+    t = fmaf(lt, input, t);
+    float nu = t / (1.0f + lt);
+    return fmaf(theta, nu - u, nu);
+}
+
+struct PdArgs {
+    const float *in;
+    const float *u_in;
+    float *u_out;
+    const void *p_in[3];
+    void *p_out[3];
+    int dx, dy;
+    int planes;       // planes addressed by the pointers (ghost planes included)
+    int out_begin;    // first plane that is written
+    int out_end;      // one past the last plane that is written
+    int first_is_edge;  // plane 0 is the global z = 0 plane
+    int last_is_edge;   // plane planes-1 is the global last plane
+    float sigma, tau, lt, theta;
+    int zchunk;       // planes per z-chunk (zmarch)
+};
+
+// ------------------------------------------------------------------------------------------ PD variant 1
+// forward difference with the far-edge mirror (primal_dual...cu:216-220) and zero "previous" at index 0 (:147-160)
+__device__ __forceinline__ float fwd_diff(const float *U, size_t idx, int i, int dim, size_t stride, bool edge_last)
+{
+    float u = U[idx];
+    float nxt;
+    if (i == dim - 1 && edge_last) nxt = (i > 0) ? U[idx - stride] : 0.0f;
+    else nxt = U[idx + stride];
+    return nxt - u;
+}
+
+template <typename T, int ND, bool ANISO>
+__device__ __forceinline__ void pd_dual_at(const PdArgs &a, int x, int y, int z, float (&p)[3])
+{
+    const size_t sy = (size_t)a.dx, sz = (size_t)a.dx * a.dy;
+    const size_t idx = (size_t)x + sy * y + sz * z;
+    float g[3] = {0.0f, 0.0f, 0.0f};
+    g[0] = fwd_diff(a.u_in, idx, x, a.dx, 1, true);
+    g[1] = fwd_diff(a.u_in, idx, y, a.dy, sy, true);
+    if (ND == 3) g[2] = fwd_diff(a.u_in, idx, z, a.planes, sz, a.last_is_edge != 0);
+#pragma unroll
+    for (int c = 0; c < ND; ++c) p[c] = DualIO<T>::ld((const T *)a.p_in[c], idx);
+    pd_dual<ND, ANISO>(p, g, a.sigma);
+}
+
+template <typename T, int ND, bool NONNEG, bool ANISO>
+__global__ __launch_bounds__(256) void pd_pervoxel_kernel(PdArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int z = a.out_begin + blockIdx.z;
+    if (x >= a.dx) return;
+    const size_t sy = (size_t)a.dx, sz = (size_t)a.dx * a.dy;
+    const size_t idx = (size_t)x + sy * y + sz * z;
+    float p[3] = {0, 0, 0}, q[3] = {0, 0, 0};
+    pd_dual_at<T, ND, ANISO>(a, x, y, z, p);
+    float px = 0.0f, py = 0.0f, pz = 0.0f;
+    if (x > 0) { pd_dual_at<T, ND, ANISO>(a, x - 1, y, z, q); px = q[0]; }
+    if (y > 0) { pd_dual_at<T, ND, ANISO>(a, x, y - 1, z, q); py = q[1]; }
+    if (ND == 3 && z > 0) { pd_dual_at<T, ND, ANISO>(a, x, y, z - 1, q); pz = q[2]; }
+    float div = (-(p[0] - px)) + (-(p[1] - py));
+    if (ND == 3) div = div + (-(p[2] - pz));
+    a.u_out[idx] = pd_primal(a.u_in[idx], a.in[idx], div, a.tau, a.lt, a.theta, NONNEG);
+#pragma unroll
+    for (int c = 0; c < ND; ++c) DualIO<T>::st((T *)a.p_out[c], idx, p[c]);
+}
+
+// ------------------------------------------------------------------------------------------ PD variant 0
+// Wave-autonomous register-blocked z-march.  Block = 4 waves stacked along y.
+//   lane l of x-segment s  <->  x = 63*s - 1 + l   (lane 0 = halo lane, lanes 1..63 produce output)
+//   row slot r in [-1, RY) <->  y = y0 + r         (slot -1 = halo row, slots 0..RY-1 produce output)
+template <typename T, int ND, bool NONNEG, bool ANISO, int RY>
+__global__ __launch_bounds__(256) void pd_zmarch_kernel(PdArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int x = (int)blockIdx.x * 63 - 1 + lane;
+    const int y0 = ((int)blockIdx.y * 4 + wave) * RY;
+    if (y0 >= a.dy) return;  // whole wave idle (no barriers in this kernel)
+    const int zc0 = a.out_begin + (int)blockIdx.z * a.zchunk;
+    const int zc1 = min(zc0 + a.zchunk, a.out_end);
+
+    const int dx = a.dx, dy = a.dy;
+    const size_t sy = (size_t)dx, sz = (size_t)dx * dy;
+    const bool x_ok = (x >= 0) && (x < dx);
+    const bool x_last = (x == dx - 1);
+    const bool x_has_prev = (x > 0);
+    const bool emit_lane = x_ok && (lane >= 1);
+    const T *P_in[3] = {(const T *)a.p_in[0], (const T *)a.p_in[1], (const T *)a.p_in[2]};
+    T *P_out[3] = {(T *)a.p_out[0], (T *)a.p_out[1], (T *)a.p_out[2]};
+
+    // row validity: slot r valid when 0 <= y0 + r < dy
+    auto row_ok = [&](int r) { int y = y0 + r; return y >= 0 && y < dy; };
+    auto ldU = [&](int plane, int r) -> float {
+        return (x_ok && row_ok(r)) ? a.u_in[(size_t)x + sy * (y0 + r) + sz * plane] : 0.0f;
+    };
+
+    float Uc[RY + 2];       // current plane, slots -1..RY  (index r+1)
+    float Un[RY + 2];       // next plane
+    float carry3[RY];       // updated P3 of the previous plane, slots 0..RY-1
+#pragma unroll
+    for (int r = 0; r < RY; ++r) carry3[r] = 0.0f;
+
+    const int zstart = (ND == 3 && zc0 > 0) ? zc0 - 1 : zc0;  // one warm-up plane to build carry3
+#pragma unroll
+    for (int r = -1; r <= RY; ++r) Uc[r + 1] = ldU(zstart, r);
+
+    for (int z = zstart; z < zc1; ++z) {
+        const bool emit_plane = (z >= zc0);
+        const bool z_last = (ND == 3) && (z == a.planes - 1) && a.last_is_edge;
+        // ---- next plane (or the mirrored previous plane at the global far edge)
+        if (ND == 3) {
+            if (!z_last) {
+#pragma unroll
+                for (int r = -1; r <= RY; ++r) Un[r + 1] = (z + 1 < a.planes) ? ldU(z + 1, r) : 0.0f;
+            } else {
+#pragma unroll
+                for (int r = -1; r <= RY; ++r) Un[r + 1] = (z > 0) ? ldU(z - 1, r) : 0.0f;
+            }
+        }
+        // ---- duals of slots -1..RY-1
+        float Pn[3][RY + 1];
+#pragma unroll
+        for (int r = -1; r < RY; ++r) {
+            const int y = y0 + r;
+            const bool ok = x_ok && row_ok(r);
+            const size_t idx = (size_t)(x_ok ? x : 0) + sy * (ok ? y : 0) + sz * z;
+            float u = Uc[r + 1];
+            // +x neighbour: lane+1, except lane 63 which fetches it (served by L2)
+            float ux = __shfl_down(u, 1, 64);
+            if (lane == 63) ux = (ok && x + 1 < dx) ? a.u_in[idx + 1] : 0.0f;
+            float uxm = __shfl_up(u, 1, 64);  // x-1 (for the far-edge mirror)
+            if (lane == 0) uxm = (ok && x > 0) ? a.u_in[idx - 1] : 0.0f;
+            float g[3] = {0.0f, 0.0f, 0.0f};
+            g[0] = (x_last ? (x_has_prev ? uxm : 0.0f) : ux) - u;
+            {
+                float uy;
+                if (y == dy - 1) uy = (y > 0) ? Uc[r >= 0 ? r : 0] : 0.0f;  // slot -1 is never the last row
+                else uy = Uc[r + 2];
+                g[1] = uy - u;
+            }
+            if (ND == 3) g[2] = Un[r + 1] - u;
+            float p[3] = {0.0f, 0.0f, 0.0f};
+            if (ok) {
+#pragma unroll
+                for (int c = 0; c < ND; ++c) p[c] = DualIO<T>::ld(P_in[c], idx);
+            }
+            pd_dual<ND, ANISO>(p, g, a.sigma);
+#pragma unroll
+            for (int c = 0; c < ND; ++c) Pn[c][r + 1] = p[c];
+        }
+        // ---- primal step for slots 0..RY-1
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const int y = y0 + r;
+            float p1l = __shfl_up(Pn[0][r + 1], 1, 64);  // updated P1 at x-1 (shuffle executed by all lanes)
+            if (emit_plane && emit_lane && y < dy) {
+                const size_t idx = (size_t)x + sy * y + sz * z;
+                float px = x_has_prev ? p1l : 0.0f;
+                float py = (y > 0) ? Pn[1][r] : 0.0f;
+                float div = (-(Pn[0][r + 1] - px)) + (-(Pn[1][r + 1] - py));
+                if (ND == 3) {
+                    float pz = (z > 0) ? carry3[r] : 0.0f;
+                    div = div + (-(Pn[2][r + 1] - pz));
+                }
+                a.u_out[idx] = pd_primal(Uc[r + 1], a.in[idx], div, a.tau, a.lt, a.theta, NONNEG);
+#pragma unroll
+                for (int c = 0; c < ND; ++c) DualIO<T>::st(P_out[c], idx, Pn[c][r + 1]);
+            }
+            if (ND == 3) carry3[r] = Pn[2][r + 1];
+        }
+        if (ND == 3) {
+#pragma unroll
+            for (int r = 0; r < RY + 2; ++r) Uc[r] = Un[r];
+        }
+    }
+}
+
+template <typename T, int ND, bool NONNEG, bool ANISO>
+int pd_launch(const PdArgs &a0, int variant, hipStream_t st)
+{
+    PdArgs a = a0;
+    const int nout = a.out_end - a.out_begin;
+    if (nout <= 0 || a.dx <= 0 || a.dy <= 0) return TOMO_OK;
+    if (variant == 1) {
+        dim3 grid(ceil_div(a.dx, 256), a.dy, nout);
+        pd_pervoxel_kernel<T, ND, NONNEG, ANISO><<<grid, 256, 0, st>>>(a);
+    } else {
+        constexpr int RY = 4;
+        // enough z-chunks to fill the chip (>= ~8 waves per SIMD) but long enough to amortise the warm-up plane
+        const int gx = ceil_div(a.dx, 63), gy = ceil_div(a.dy, 4 * RY);
+        int chunks = 1;
+        if (ND == 3) {
+            const long waves_xy = (long)gx * gy * 4;
+            const long want = 256L * 4 * 8;
+            chunks = (int)((want + waves_xy - 1) / waves_xy);
+            if (chunks < 1) chunks = 1;
+            int max_chunks = ceil_div(nout, 16);
+            if (chunks > max_chunks) chunks = max_chunks;
+            if (chunks < 1) chunks = 1;
+        }
+        a.zchunk = ceil_div(nout, chunks);
+        chunks = ceil_div(nout, a.zchunk);
+        dim3 grid(gx, gy, chunks);
+        pd_zmarch_kernel<T, ND, NONNEG, ANISO, RY><<<grid, 256, 0, st>>>(a);
+    }
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
+template <typename T, int ND>
+int pd_dispatch(const PdArgs &a, int methodTV, int nonneg, int variant, hipStream_t st)
+{
+    if (!nonneg && !methodTV) return pd_launch<T, ND, false, false>(a, variant, st);
+    if (nonneg && !methodTV) return pd_launch<T, ND, true, false>(a, variant, st);
+    if (!nonneg && methodTV) return pd_launch<T, ND, false, true>(a, variant, st);
+    return pd_launch<T, ND, true, true>(a, variant, st);
+}
+
+int pd_iter(const PdArgs &a, int nd, int methodTV, int nonneg, int half, hipStream_t st)
+{
+    const int v = g_variant_pdtv;
+    if (nd == 3) return half ? pd_dispatch<__half, 3>(a, methodTV, nonneg, v, st) : pd_dispatch<float, 3>(a, methodTV, nonneg, v, st);
+    return half ? pd_dispatch<__half, 2>(a, methodTV, nonneg, v, st) : pd_dispatch<float, 2>(a, methodTV, nonneg, v, st);
+}
+
+// ------------------------------------------------------------------------------------------ ROF
+struct RofArgs {
+    const float *in;
+    const float *u_in;
+    float *u_out;
+    int dx, dy, planes, out_begin, out_end;
+    int first_is_edge, last_is_edge;
+    float lambda, tau;
+};
+
+__device__ __forceinline__ float rof_mm(float n0, float n1)
+{
+    // (0.5*(sign(n1)+sign(n0)) * min(|n1|,|n0|))^2   (rudin_osher...cu:51-55)
+    int sg = ((n1 > 0.0f) - (n1 < 0.0f)) + ((n0 > 0.0f) - (n0 < 0.0f));
+    float m = fminf(fabsf(n1), fabsf(n0));
+    m = (sg == 0) ? 0.0f : (sg > 0 ? m : -m);
+    return m * m;
+}
+
+__device__ __forceinline__ float rof_norm(float nom, float d1, float d2, float d3)
+{
+    float s = (d1 + d2) + d3;
+    float den = sqrtf((float)((double)s + 1.0e-8));  // EPS is a double literal in the reference (:7,:59)
+    return nom / den;
+}
+
+// D component `comp` (0: pairs with y/j, 1: with x/i, 2: with z/k) at voxel (i,j,k)
+template <int ND, bool HALF>
+__device__ __forceinline__ float rof_D(const RofArgs &a, int i, int j, int k, int comp)
+{
+    const size_t sy = (size_t)a.dx, sz = (size_t)a.dx * a.dy;
+    const float *U = a.u_in;
+    const int i1 = (i == a.dx - 1) ? i - 1 : i + 1, i2 = (i == 0) ? i + 1 : i - 1;
+    const int j1 = (j == a.dy - 1) ? j - 1 : j + 1, j2 = (j == 0) ? j + 1 : j - 1;
+    const size_t base = sz * k;
+    const float u = U[base + sy * j + i];
+    const float nx1 = U[base + sy * j1 + i] - u, nx0 = u - U[base + sy * j2 + i];
+    const float ny1 = U[base + sy * j + i1] - u, ny0 = u - U[base + sy * j + i2];
+    const float dxm = rof_mm(nx0, nx1), dym = rof_mm(ny0, ny1);
+    float nz1 = 0.0f, dzm = 0.0f;
+    if (ND == 3) {
+        const bool k_last = (k == a.planes - 1) && a.last_is_edge;
+        const bool k_first = (k == 0) && a.first_is_edge;
+        const int k1 = k_last ? k - 1 : k + 1, k2 = k_first ? k + 1 : k - 1;
+        nz1 = U[sz * k1 + sy * j + i] - u;
+        const float nz0 = u - U[sz * k2 + sy * j + i];
+        dzm = rof_mm(nz0, nz1);
+    }
+    float d;
+    if (comp == 0) d = rof_norm(nx1, nx1 * nx1, dym, dzm);
+    else if (comp == 1) d = rof_norm(ny1, dxm, ny1 * ny1, dzm);
+    else d = rof_norm(nz1, dxm, dym, nz1 * nz1);
+    return HALF ? DualIO<__half>::rt(d) : d;
+}
+
+template <int ND, bool HALF>
+__global__ __launch_bounds__(256) void rof_pervoxel_kernel(RofArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    const int k = a.out_begin + blockIdx.z;
+    if (i >= a.dx) return;
+    const size_t idx = (size_t)i + (size_t)a.dx * j + (size_t)a.dx * a.dy * k;
+    const int i2 = (i == 0) ? i + 1 : i - 1;
+    const int j2 = (j == 0) ? j + 1 : j - 1;
+    float dv = (rof_D<ND, HALF>(a, i, j, k, 0) - rof_D<ND, HALF>(a, i, j2, k, 0)) +
+               (rof_D<ND, HALF>(a, i, j, k, 1) - rof_D<ND, HALF>(a, i2, j, k, 1));
+    if (ND == 3) {
+        const bool k_first = (k == 0) && a.first_is_edge;
+        const int k2 = k_first ? k + 1 : k - 1;
+        dv = dv + (rof_D<ND, HALF>(a, i, j, k, 2) - rof_D<ND, HALF>(a, i, j, k2, 2));
+    }
+    const float u = a.u_in[idx];
+    const float t = fmaf(a.lambda, dv, -(u - a.in[idx]));
+    a.u_out[idx] = fmaf(a.tau, t, u);
+}
+
+int rof_iter(const RofArgs &a, int nd, int half, hipStream_t st)
+{
+    const int nout = a.out_end - a.out_begin;
+    if (nout <= 0) return TOMO_OK;
+    dim3 grid(ceil_div(a.dx, 256), a.dy, nout);
+    if (nd == 3) {
+        if (half) rof_pervoxel_kernel<3, true><<<grid, 256, 0, st>>>(a);
+        else rof_pervoxel_kernel<3, false><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (half) rof_pervoxel_kernel<2, true><<<grid, 256, 0, st>>>(a);
+        else rof_pervoxel_kernel<2, false><<<grid, 256, 0, st>>>(a);
+    }
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C-ABI
+extern "C" size_t tomo_pdtv_scratch_bytes(int dx, int dy, int dz, int nd, int half)
+{
+    if (nd == 2) dz = 1;
+    const size_t nvox = (size_t)dx * dy * dz;
+    const size_t ub = align_up(nvox * sizeof(float), 256);
+    const size_t pb = align_up(nvox * (half ? 2 : 4), 256);
+    return 2 * ub + 2 * (size_t)nd * pb;
+}
+
+extern "C" size_t tomo_roftv_scratch_bytes(int dx, int dy, int dz, int nd)
+{
+    if (nd == 2) dz = 1;
+    return 2 * align_up((size_t)dx * dy * dz * sizeof(float), 256);
+}
+
+extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx, int dy, int dz, int nd,
+                         float sigma, float tau, float lt, float theta, int iters, int methodTV, int nonneg,
+                         int half, void *stream)
+{
+    TOMO_REQUIRE(device >= 0, "The gpu_device must be a positive integer or zero");
+    TOMO_REQUIRE(nd == 2 || nd == 3, "2D or 3D arrays must be provided only");
+    if (nd == 2) dz = 1;
+    TOMO_REQUIRE(dx > 0 && dy > 0 && dz > 0 && iters >= 0, "bad PD_TV dimensions / iterations");
+    TOMO_REQUIRE(in_dev && out_dev, "NULL data pointer");
+    TOMO_HIP(hipSetDevice(device));
+    hipStream_t st = as_stream(stream);
+    const size_t nvox = (size_t)dx * dy * dz;
+    if (iters == 0) {
+        if (out_dev != in_dev) TOMO_HIP(hipMemcpyAsync(out_dev, in_dev, nvox * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return TOMO_OK;
+    }
+    void *base = nullptr;
+    int rc = tomo_arena_get(device, tomo_pdtv_scratch_bytes(dx, dy, dz, nd, half), &base);
+    if (rc != TOMO_OK) return rc;
+    const size_t ub = align_up(nvox * sizeof(float), 256);
+    const size_t pb = align_up(nvox * (half ? 2 : 4), 256);
+    char *cur = (char *)base;
+    float *U[2];
+    void *P[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    U[0] = (float *)cur; cur += ub;
+    U[1] = (float *)cur; cur += ub;
+    for (int b = 0; b < 2; ++b)
+        for (int c = 0; c < nd; ++c) { P[b][c] = cur; cur += pb; }
+    // U_arrays[0] = data.copy() is not materialised: iteration 0 reads the caller's buffer directly;
+    // duals start at zero (regularisersCuPy.py:221-223); every U / P output buffer is fully overwritten
+    for (int c = 0; c < nd; ++c) TOMO_HIP(hipMemsetAsync(P[0][c], 0, pb, st));
+    for (int it = 0; it < iters; ++it) {
+        const int ib = it & 1, ob = ib ^ 1;
+        PdArgs a;
+        a.in = in_dev;
+        a.u_in = (it == 0) ? in_dev : U[ib];
+        // the last iteration writes straight into the caller's output buffer (unless it aliases the input)
+        a.u_out = (it == iters - 1 && out_dev != in_dev) ? out_dev : U[ob];
+        for (int c = 0; c < 3; ++c) { a.p_in[c] = P[ib][c]; a.p_out[c] = P[ob][c]; }
+        a.dx = dx; a.dy = dy; a.planes = dz; a.out_begin = 0; a.out_end = dz;
+        a.first_is_edge = 1; a.last_is_edge = 1;
+        a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = dz;
+        rc = pd_iter(a, nd, methodTV, nonneg, half, st);
+        if (rc != TOMO_OK) return rc;
+    }
+    if (out_dev == in_dev)
+        TOMO_HIP(hipMemcpyAsync(out_dev, U[iters & 1], nvox * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_pdtv_iter_slab(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
+                                   const void *p_in_dev[3], void *p_out_dev[3], int dx, int dy, int nz_local,
+                                   int has_lo, int has_hi, float sigma, float tau, float lt, float theta,
+                                   int methodTV, int nonneg, int half, void *stream)
+{
+    TOMO_REQUIRE(device >= 0 && dx > 0 && dy > 0 && nz_local > 0, "bad slab arguments");
+    TOMO_HIP(hipSetDevice(device));
+    PdArgs a;
+    a.in = in_dev; a.u_in = u_in_dev; a.u_out = u_out_dev;
+    for (int c = 0; c < 3; ++c) { a.p_in[c] = p_in_dev[c]; a.p_out[c] = p_out_dev[c]; }
+    a.dx = dx; a.dy = dy;
+    a.planes = nz_local + (has_lo ? 1 : 0) + (has_hi ? 1 : 0);
+    a.out_begin = has_lo ? 1 : 0;
+    a.out_end = a.out_begin + nz_local;
+    a.first_is_edge = has_lo ? 0 : 1;
+    a.last_is_edge = has_hi ? 0 : 1;
+    a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = nz_local;
+    return pd_iter(a, 3, methodTV, nonneg, half, as_stream(stream));
+}
+
+extern "C" int tomo_roftv(int device, const float *in_dev, float *out_dev, int dx, int dy, int dz, int nd,
+                          float lambda, float tau, int iters, int half, void *stream)
+{
+    TOMO_REQUIRE(device >= 0, "The gpu_device must be a positive integer or zero");
+    TOMO_REQUIRE(nd == 2 || nd == 3, "2D or 3D arrays must be provided only");
+    if (nd == 2) dz = 1;
+    TOMO_REQUIRE(dx >= 2 && dy >= 2 && (nd == 2 || dz >= 2) && iters >= 0,
+                 "ROF_TV needs every dimension >= 2 (reflecting boundary)");
+    TOMO_REQUIRE(in_dev && out_dev, "NULL data pointer");
+    TOMO_HIP(hipSetDevice(device));
+    hipStream_t st = as_stream(stream);
+    const size_t nvox = (size_t)dx * dy * dz;
+    if (iters == 0) {
+        if (out_dev != in_dev) TOMO_HIP(hipMemcpyAsync(out_dev, in_dev, nvox * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return TOMO_OK;
+    }
+    void *base = nullptr;
+    int rc = tomo_arena_get(device, tomo_roftv_scratch_bytes(dx, dy, dz, nd), &base);
+    if (rc != TOMO_OK) return rc;
+    const size_t ub = align_up(nvox * sizeof(float), 256);
+    float *U[2] = {(float *)base, (float *)((char *)base + ub)};
+    for (int it = 0; it < iters; ++it) {
+        RofArgs a;
+        a.in = in_dev;
+        a.u_in = (it == 0) ? in_dev : U[it & 1];  // iteration 0 reads the caller's data directly
+        a.u_out = (it == iters - 1 && out_dev != in_dev) ? out_dev : U[(it + 1) & 1];
+        a.dx = dx; a.dy = dy; a.planes = dz; a.out_begin = 0; a.out_end = dz;
+        a.first_is_edge = 1; a.last_is_edge = 1;
+        a.lambda = lambda; a.tau = tau;
+        rc = rof_iter(a, nd, half, st);
+        if (rc != TOMO_OK) return rc;
+    }
+    if (out_dev == in_dev)
+        TOMO_HIP(hipMemcpyAsync(out_dev, U[iters & 1], nvox * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return TOMO_OK;
+}
+
+extern "C" int tomo_roftv_iter_slab(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
+                                    int dx, int dy, int nz_local, int lo_planes, int hi_planes,
+                                    float lambda, float tau, int half, void *stream)
+{
+    TOMO_REQUIRE(device >= 0 && dx >= 2 && dy >= 2 && nz_local > 0, "bad slab arguments");
+    TOMO_REQUIRE((lo_planes == 0 || lo_planes == 2) && (hi_planes == 0 || hi_planes == 1),
+                 "ROF slab needs 0 or 2 ghost planes below and 0 or 1 above");
+    TOMO_HIP(hipSetDevice(device));
+    RofArgs a;
+    a.in = in_dev; a.u_in = u_in_dev; a.u_out = u_out_dev;
+    a.dx = dx; a.dy = dy;
+    a.planes = nz_local + lo_planes + hi_planes;
+    a.out_begin = lo_planes;
+    a.out_end = lo_planes + nz_local;
+    a.first_is_edge = lo_planes ? 0 : 1;
+    a.last_is_edge = hi_planes ? 0 : 1;
+    a.lambda = lambda; a.tau = tau;
+    return rof_iter(a, 3, half, as_stream(stream));
+}

@@ -1,0 +1,169 @@
+"""Tensor-level wrappers over the C-ABI: device memory and streams come from torch (plumbing only),
+every arithmetic operation is a HIP kernel in ``libtomo_mi355x.so``.
+
+Arrays are ``torch.Tensor`` (float32, device ``cuda:<index>``) where the reference uses ``cupy.ndarray``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _require_gpu(device_index: int) -> torch.device:
+    if not torch.cuda.is_available():
+        raise L.TomoRuntimeError(
+            "no ROCm device is visible to torch: tomobar_amd runs on MI355X (gfx950) only and has no CPU fallback")
+    return torch.device("cuda", int(device_index))
+
+
+def to_device(x, device_index: int = 0) -> torch.Tensor:
+    """numpy / torch / __cuda_array_interface__ object -> float32-preserving device tensor (no dtype change)."""
+    dev = _require_gpu(device_index)
+    if isinstance(x, torch.Tensor):
+        return x.to(dev)
+    if isinstance(x, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    return torch.as_tensor(x, device=dev)
+
+
+def stream_ptr(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk_f32(t: torch.Tensor, name="array"):
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be C-contiguous")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU")
+
+
+def contiguous(t: torch.Tensor) -> torch.Tensor:
+    """Materialise a (possibly permuted) <=3-D float32 view as a C-contiguous tensor with tomo_permute3."""
+    if t.is_contiguous():
+        return t
+    if t.dtype != torch.float32 or t.dim() > 3:
+        raise ValueError("only float32 arrays of at most 3 dimensions are supported")
+    shape = list(t.shape)
+    strides = list(t.stride())
+    while len(shape) < 3:
+        shape.insert(0, 1)
+        strides.insert(0, 0)
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        L.check(L.lib().tomo_permute3(ptr(t), ptr(out), shape[0], shape[1], shape[2],
+                                      strides[0], strides[1], strides[2], stream_ptr(t)))
+    return out
+
+
+# ----------------------------------------------------------------------------- element-wise / reductions
+def momentum(x, x_old, x_t, beta):
+    L.check(L.lib().tomo_momentum(ptr(x), ptr(x_old), ptr(x_t), float(beta), x.numel(), stream_ptr(x)))
+
+
+def admm_dual(u, z, x):
+    L.check(L.lib().tomo_admm_dual(ptr(u), ptr(z), ptr(x), u.numel(), stream_ptr(u)))
+
+
+def axpby(a, x, b, y):
+    L.check(L.lib().tomo_axpby(float(a), ptr(x), float(b), ptr(y), y.numel(), stream_ptr(y)))
+
+
+def scale(a, x, y):
+    L.check(L.lib().tomo_scale(float(a), ptr(x), ptr(y), y.numel(), stream_ptr(y)))
+
+
+def clamp_min(x, lo=0.0):
+    L.check(L.lib().tomo_clamp_min(ptr(x), float(lo), x.numel(), stream_ptr(x)))
+
+
+def mul(x, y):
+    L.check(L.lib().tomo_mul(ptr(x), ptr(y), y.numel(), stream_ptr(y)))
+
+
+def recip_safe(x, y):
+    L.check(L.lib().tomo_recip_safe(ptr(x), ptr(y), y.numel(), stream_ptr(y)))
+
+
+def fill(x, value):
+    L.check(L.lib().tomo_fill(ptr(x), float(value), x.numel(), stream_ptr(x)))
+
+
+def norm2(x) -> float:
+    out = C.c_double(0.0)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().tomo_norm2(ptr(x), x.numel(), C.byref(out), stream_ptr(x)))
+    return out.value
+
+
+def dot(x, y) -> float:
+    out = C.c_double(0.0)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().tomo_dot(ptr(x), ptr(y), x.numel(), C.byref(out), stream_ptr(x)))
+    return out.value
+
+
+def pwls_weights(b):
+    w = torch.empty_like(b)
+    with torch.cuda.device(b.device):
+        L.check(L.lib().tomo_pwls_weights(ptr(b), ptr(w), b.numel(), stream_ptr(b)))
+    return w
+
+
+# ----------------------------------------------------------------------------- pre / post
+def pad_edge(b, pad):
+    nz, na, nu0 = b.shape
+    out = torch.empty((nz, na, nu0 + 2 * pad), dtype=torch.float32, device=b.device)
+    L.check(L.lib().tomo_pad_edge(ptr(b), ptr(out), nz * na, nu0, pad, stream_ptr(b)))
+    return out
+
+
+def crop_center(vol, m):
+    nz, n, _ = vol.shape
+    out = torch.empty((nz, m, m), dtype=torch.float32, device=vol.device)
+    L.check(L.lib().tomo_crop_center(ptr(vol), ptr(out), nz, n, m, stream_ptr(vol)))
+    return out
+
+
+def circ_mask_(vol, radius):
+    nz, n, _ = vol.shape
+    L.check(L.lib().tomo_circ_mask(ptr(vol), nz, n, float(radius), stream_ptr(vol)))
+    return vol
+
+
+# ----------------------------------------------------------------------------- TV
+def _tv_dims(t):
+    if t.dim() == 2:
+        return t.shape[1], t.shape[0], 1, 2
+    return t.shape[2], t.shape[1], t.shape[0], 3
+
+
+def pdtv(data, out, sigma, tau, lt, theta, iterations, methodTV, nonneg, half):
+    dx, dy, dz, nd = _tv_dims(data)
+    with torch.cuda.device(data.device):
+        L.check(L.lib().tomo_pdtv(data.device.index, ptr(data), ptr(out), dx, dy, dz, nd, float(sigma), float(tau),
+                                  float(lt), float(theta), int(iterations), int(bool(methodTV)), int(bool(nonneg)),
+                                  int(bool(half)), stream_ptr(data)))
+    return out
+
+
+def roftv(data, out, lam, tau, iterations, half):
+    dx, dy, dz, nd = _tv_dims(data)
+    with torch.cuda.device(data.device):
+        L.check(L.lib().tomo_roftv(data.device.index, ptr(data), ptr(out), dx, dy, dz, nd, float(lam), float(tau),
+                                   int(iterations), int(bool(half)), stream_ptr(data)))
+    return out
+
+
+def set_variant(kernel: str, variant: int):
+    L.check(L.lib().tomo_set_variant(kernel.encode(), int(variant)))
