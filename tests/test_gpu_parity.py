@@ -1,0 +1,294 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libtomo_mi355x.so) against the CPU oracle on the same
+seeded inputs, and against the committed golden fixtures.  Tolerance: 1e-5 relative L2 (BASELINE.json north_star);
+where the kernels reproduce the oracle's rounding sequence the tests also report / require bit-exactness."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tomobar_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(autouse=True)
+def _reset_variants(ops):
+    yield
+    for k in ("bp", "fp", "pdtv", "roftv"):
+        ops.set_variant(k, 0)
+
+
+# ------------------------------------------------------------------------------------------ projector pair
+GEOMS = [
+    # nz, n, nu, na, cor, os
+    (5, 40, 40, 24, 0.0, 1),
+    (3, 37, 45, 19, 1.25, 1),       # odd sizes, detector wider than the grid, CoR offset
+    (18, 70, 64, 31, -2.5, 4),      # several z-batches, detector narrower than the grid, OS with a trimmed subset
+    (1, 130, 130, 50, 0.0, 7),      # single slice (2D case), >2 x-tiles
+    (33, 24, 24, 9, "vec", 2),      # per-angle CoR vector, nz not a multiple of 16
+]
+
+
+def make_pair(oracle, g, flags=0):
+    from tomobar_amd.projector import HipTools3D
+    nz, n, nu, na, cor, os_n = g
+    angles = np.linspace(0.1, np.pi + 0.1, na, endpoint=False)
+    if isinstance(cor, str):
+        cor = np.linspace(-1.5, 2.0, na)
+    P = oracle.Projector(nz, n, nu, angles, cor, os_n, flags=flags)
+    H = HipTools3D(nu, 0, nz, angles, cor, n, "gpu", 0, os_n if os_n > 1 else None, lerp8=bool(flags))
+    return P, H
+
+
+@pytest.mark.parametrize("g", GEOMS)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_backprojection_vs_oracle(oracle, ops, g, variant):
+    P, H = make_pair(oracle, g)
+    ops.set_variant("bp", variant)
+    rng = np.random.default_rng(1)
+    subsets = [None] if P.os_number == 1 else list(range(P.os_number))
+    for s in subsets:
+        nsel = len(P.subsets[s]) if s is not None else P.na
+        sino = rng.standard_normal((P.nz, nsel, P.nu)).astype(np.float32)
+        want = P.bp(sino, s)
+        got = host(H.backward(dev(sino), s))
+        assert got.shape == want.shape
+        assert rel(got, want) < 1e-6, (g, variant, s, rel(got, want))
+        assert np.array_equal(got, want), f"BP not bit-identical: max abs {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("g", GEOMS)
+def test_forward_projection_vs_oracle(oracle, ops, g):
+    P, H = make_pair(oracle, g)
+    rng = np.random.default_rng(2)
+    vol = rng.standard_normal((P.nz, P.n, P.n)).astype(np.float32)
+    subsets = [None] if P.os_number == 1 else list(range(P.os_number))
+    for s in subsets:
+        want = P.fp(vol, s)
+        got = host(H.forward(dev(vol), s))
+        assert got.shape == want.shape
+        assert rel(got, want) < 1e-6, (g, s, rel(got, want))
+        assert np.array_equal(got, want), f"FP not bit-identical: max abs {np.abs(got - want).max()}"
+
+
+def test_lerp8_mode_and_reference_literals(oracle, ops):
+    """tests/test_RecToolsDIRCuPy.py:671-694 of the reference: ones(128,160,160) -> min 67.27458 max 225.27428."""
+    from tomobar_amd.projector import HipTools3D
+    angles = np.deg2rad(np.arange(180.0))
+    H = HipTools3D(160, 0, 8, angles, 0.0, 160, "gpu", 0, None, lerp8=True)
+    s = host(H.forward(torch.ones((8, 160, 160), dtype=torch.float32, device="cuda")))
+    np.testing.assert_allclose(s.min(), 67.27458, rtol=2e-6)
+    np.testing.assert_allclose(s.max(), 225.27428, rtol=2e-6)
+    P = oracle.Projector(8, 160, 160, angles, flags=oracle.FLAG_LERP8)
+    sino = np.random.default_rng(0).random((8, 180, 160)).astype(np.float32)
+    for v in (0, 1):
+        ops.set_variant("bp", v)
+        assert rel(host(H.backward(dev(sino))), P.bp(sino)) < 1e-6
+
+
+def test_power_method_literals(oracle):
+    """tests/test_RecToolsIRCuPy.py:316,573,639 of the reference."""
+    from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    angles = np.deg2rad(np.arange(180.0))
+    dummy = {"projection_data": None}
+    for pad, os_n, literal in ((0, None, 27550.463), (0, 5, 5510.867), (60, 5, 9644.283)):
+        rt = RecToolsIRCuPy(160, pad, 4, 0.0, angles, 160, 0, os_n)
+        rt.power_seed = 0
+        np.testing.assert_allclose(rt.powermethod(dict(dummy)), literal, rtol=1e-5)
+
+
+def test_fused_residual_and_gradient_steps(oracle, ops):
+    g = (6, 36, 40, 22, 0.5, 3)
+    P, H = make_pair(oracle, g)
+    rng = np.random.default_rng(3)
+    b = rng.random((P.nz, P.na, P.nu)).astype(np.float32)
+    w = oracle.pwls_weights(b)
+    x = rng.random((P.nz, P.n, P.n)).astype(np.float32) * 0.05
+    xo = rng.random((P.nz, P.n, P.n)).astype(np.float32) * 0.05
+    u = rng.standard_normal((P.nz, P.n, P.n)).astype(np.float32) * 0.01
+    wd = ops.pwls_weights(dev(b))
+    assert np.array_equal(host(wd), w)
+    for s in range(3):
+        idx = P.subsets[s]
+        ax = P.fp(x, s)
+        res = torch.empty(H.sino_shape(s), dtype=torch.float32, device="cuda")
+        for fid, want in (("LS", ax - b[:, idx]), ("PWLS", (ax - b[:, idx]) * w[:, idx]),
+                          ("KL", np.float32(1) - b[:, idx] / np.clip(ax, np.float32(1e-8), None))):
+            H.residual(dev(x), dev(b), wd if fid == "PWLS" else None, fid, s, res)
+            assert np.array_equal(host(res), want.astype(np.float32)), fid
+        # gradient step epilogues
+        r = (ax - b[:, idx]).astype(np.float32)
+        grad = P.bp(r, s)
+        linv, beta = np.float32(1 / 300.0), np.float32(0.37)
+        for variant in (0, 1):
+            ops.set_variant("bp", variant)
+            for nonneg in (False, True):
+                X = x - linv * grad
+                if nonneg:
+                    X = np.maximum(X, 0)
+                out = torch.empty_like(dev(x))
+                H.grad_step(dev(r), dev(x), out, linv, nonneg, s)
+                assert np.array_equal(host(out), X)
+                xt_d, xo_d = dev(x), dev(xo)
+                H.grad_step_momentum(dev(r), xt_d, xo_d, linv, beta, nonneg, s)
+                assert np.array_equal(host(xo_d), X)
+                assert np.array_equal(host(xt_d), X + beta * (X - xo))
+            # ADMM z-update (z = x here), with and without relaxation
+            tau, rho, al = np.float32(0.002), np.float32(1.7), 1.6
+            for relax_on in (False, True):
+                z = x.copy()
+                ga = rho * (z - xo + u)
+                zn = z - tau * (grad + ga)
+                zn = np.maximum(zn, 0)
+                if relax_on:
+                    zn = np.float32(1.0 - al) * z + np.float32(al) * zn
+                z_d, zu_d = dev(x), torch.empty_like(dev(x))
+                H.admm_z_update(dev(r), z_d, dev(xo), dev(u), zu_d, tau, rho, relax_on, np.float32(1.0 - al),
+                                np.float32(al), True, s)
+                assert np.array_equal(host(z_d), zn)
+                assert np.array_equal(host(zu_d), zn + u)
+
+
+# ------------------------------------------------------------------------------------------ TV operators
+TV_SHAPES = [(6, 9, 13), (1, 20, 17), (12, 1, 70), (10, 11, 1), (8, 8, 8), (3, 5, 131), (24, 19), (20, 70, 150)]
+
+
+@pytest.mark.parametrize("shape", TV_SHAPES)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_pdtv_vs_oracle(oracle, ops, shape, variant):
+    from tomobar_amd.regularisersCuPy import PD_TV_cupy
+    ops.set_variant("pdtv", variant)
+    rng = np.random.default_rng(5)
+    x = (rng.random(shape) * 0.3 + (np.indices(shape)[-1] > shape[-1] // 2)).astype(np.float32)
+    for half in (False, True):
+        for mtv in (0, 1):
+            for nn in (0, 1):
+                xi = (x - 0.6).astype(np.float32) if nn else x
+                want = oracle.pd_tv(xi, 0.04, 11, mtv, nn, 8.0, half)
+                got = host(PD_TV_cupy(dev(xi), 0.04, 11, mtv, nn, 8.0, 0, half))
+                assert got.shape == want.shape and got.dtype == np.float32
+                assert rel(got, want) < 1e-6, (shape, variant, half, mtv, nn, rel(got, want))
+                assert np.array_equal(got, want), (shape, variant, half, mtv, nn, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("shape", TV_SHAPES)
+def test_roftv_vs_oracle(oracle, ops, shape):
+    from tomobar_amd.regularisersCuPy import ROF_TV_cupy
+    rng = np.random.default_rng(6)
+    x = (rng.random(shape) * 0.3 + (np.indices(shape)[-1] > shape[-1] // 2)).astype(np.float32)
+    for half in (False, True):
+        want = oracle.rof_tv(x, 0.05, 11, 0.005, half)
+        got = host(ROF_TV_cupy(dev(x), 0.05, 11, 0.005, 0, half))
+        assert got.shape == want.shape
+        assert rel(got, want) < 1e-6, (shape, half, rel(got, want))
+        assert np.array_equal(got, want), (shape, half, np.abs(got - want).max())
+
+
+def test_tv_against_reference_fixtures(golden_dir, ops):
+    """tests/golden/tv_golden.npz: outputs of the reference's own kernel sources (see make_tv_golden.py)."""
+    from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
+    tv = np.load(os.path.join(golden_dir, "tv_golden.npz"))
+    n = 0
+    for key in tv.files:
+        if not key.endswith("_meta"):
+            continue
+        kind, cid = key.split("_")[0], key.split("_")[1]
+        m = tv[key]
+        x = tv[f"in_{int(m[0])}"]
+        if kind == "pd":
+            _, half, mtv, nn, iters, lam, lip = m
+            xi = (x - 0.6).astype(np.float32) if nn else x
+            got = host(PD_TV_cupy(dev(xi), float(lam), int(iters), int(mtv), int(nn), float(lip), 0, bool(half)))
+        else:
+            _, half, iters, lam, tms = m
+            got = host(ROF_TV_cupy(dev(x), float(lam), int(iters), float(tms), 0, bool(half)))
+        for build in ("off", "fma"):
+            assert rel(got, tv[f"{kind}_{cid}_{build}"]) < TOL, (key, build)
+        n += 1
+    assert n > 60
+
+
+def test_tv_errors_and_2d_squeeze():
+    """regularisersCuPy.py:67,73,208,315 and tests/test_regularisers.py:7-36 of the reference."""
+    from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy, _check_if_input_2d_or_3d
+    for shape, want in (((100, 100), ((100, 100), True, 0)), ((10, 100, 100), ((10, 100, 100), False, 0)),
+                        ((1, 100, 100), ((100, 100), True, 0)), ((16, 1, 100), ((16, 100), True, 1))):
+        d, flag, ax = _check_if_input_2d_or_3d(torch.zeros(shape, dtype=torch.float32, device="cuda"))
+        assert (tuple(d.shape), flag, ax) == want
+    with pytest.raises(ValueError):
+        PD_TV_cupy(torch.zeros((4, 4), dtype=torch.float64, device="cuda"))
+    with pytest.raises(ValueError):
+        ROF_TV_cupy(torch.zeros((4, 4), dtype=torch.float32, device="cuda"), gpu_id=-1)
+    with pytest.raises(ValueError):
+        PD_TV_cupy(torch.zeros((2, 2, 2, 2), dtype=torch.float32, device="cuda"))
+    out = PD_TV_cupy(torch.rand((16, 1, 40), dtype=torch.float32, device="cuda"), 0.05, 5)
+    assert tuple(out.shape) == (16, 1, 40) and out.dtype == torch.float32
+
+
+# ------------------------------------------------------------------------------------------ glue kernels
+def test_glue_kernels(ops):
+    rng = np.random.default_rng(7)
+    for n in (1, 5, 1024, 4099):
+        x = rng.standard_normal(n).astype(np.float32)
+        y = rng.standard_normal(n).astype(np.float32)
+        z = rng.standard_normal(n).astype(np.float32)
+        beta = np.float32(0.731)
+        out = torch.empty(n, dtype=torch.float32, device="cuda")
+        ops.momentum(dev(x), dev(y), out, beta)
+        assert np.array_equal(host(out), x + beta * (x - y))
+        u = dev(x)
+        ops.admm_dual(u, dev(y), dev(z))
+        assert np.array_equal(host(u), x + (y - z))
+        yy = dev(y)
+        ops.axpby(np.float32(0.3), dev(x), np.float32(-1.1), yy)
+        assert np.array_equal(host(yy), np.float32(0.3) * x + np.float32(-1.1) * y)
+        np.testing.assert_allclose(ops.norm2(dev(x)), np.linalg.norm(x.astype(np.float64)), rtol=1e-12)
+        np.testing.assert_allclose(ops.dot(dev(x), dev(y)), np.dot(x.astype(np.float64), y.astype(np.float64)),
+                                   rtol=1e-9, atol=1e-12)
+        # unaligned views take the scalar path
+        if n > 8:
+            big = dev(np.concatenate([x, x]))
+            v = big[1:n]
+            ops.clamp_min(v, 0.0)
+            assert np.array_equal(host(v), np.maximum(x[1:], 0))
+    r = dev(np.array([0.0, 2.0, -4.0, np.inf, np.nan], np.float32))
+    o = torch.empty_like(r)
+    ops.recip_safe(r, o)
+    assert host(o).tolist() == [1.0, 0.5, -0.25, 0.0, 1.0]
+
+
+def test_pad_crop_mask_permute(oracle, ops):
+    rng = np.random.default_rng(8)
+    b = rng.random((3, 7, 10)).astype(np.float32)
+    assert np.array_equal(host(ops.pad_edge(dev(b), 4)), oracle.pad_detector(b, 4))
+    v = rng.standard_normal((3, 21, 21)).astype(np.float32)
+    assert np.array_equal(host(ops.crop_center(dev(v), 12)), oracle.crop_recon(v, 12))
+    for n in (20, 21):
+        v = rng.standard_normal((2, n, n)).astype(np.float32)
+        for radius in (0.85, 1.0, 0.5, 2.0):
+            assert np.array_equal(host(ops.circ_mask_(dev(v), radius)), oracle.circular_mask(v, radius).astype(np.float32))
+    t = dev(rng.random((4, 5, 6)).astype(np.float32))
+    for perm in ((1, 0, 2), (2, 1, 0), (0, 2, 1), (2, 0, 1)):
+        assert np.array_equal(host(ops.contiguous(t.permute(*perm))), np.ascontiguousarray(host(t).transpose(perm)))

@@ -1,0 +1,203 @@
+"""End-to-end parity of the drop-in classes: RecToolsIRCuPy.{FISTA, ADMM, powermethod, ...} on the MI355X against
+(a) tests/golden/outer_golden.npz -- outputs of the REFERENCE's own Python loops (see make_outer_golden.py) -- and
+(b) the CPU oracle on the same inputs.  The tests are written the way the reference's tests/test_RecToolsIRCuPy.py
+are: build the class from the geometry, fill the three dictionaries, call the method, check shape/dtype/values."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def outer(golden_dir):
+    return np.load(os.path.join(golden_dir, "outer_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def geom(outer):
+    sino, angles = outer["sino"], outer["angles"]
+    nz, na, n = sino.shape
+    return dict(sino=sino, angles=angles, nz=nz, n=n, na=na)
+
+
+def make(geom, pad=0, detV="3d", cor=0.0, os_number=None):
+    from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    return RecToolsIRCuPy(DetectorsDimH=geom["n"], DetectorsDimH_pad=pad,
+                          DetectorsDimV=geom["nz"] if detV == "3d" else None, CenterRotOffset=cor,
+                          AnglesVec=geom["angles"], ObjSize=geom["n"], device_projector=0, OS_number=os_number)
+
+
+def data_dict(geom, **extra):
+    d = {"projection_data": torch.from_numpy(geom["sino"]).cuda(), "data_axes_labels_order": ["detY", "angles", "detX"]}
+    d.update(extra)
+    return d
+
+
+CASES = {
+    "fista_plain": ("FISTA", {}, {}, dict(iterations=6, lipschitz_const="L_full"), None),
+    "fista_nonneg_mask": ("FISTA", {}, {}, dict(iterations=5, lipschitz_const="L_full", nonnegativity=True,
+                                                recon_mask_radius=0.85), None),
+    "fista_os4_pdtv": ("FISTA", dict(os_number=4), {}, dict(iterations=3, lipschitz_const="L_os4", nonnegativity=True),
+                       dict(method="PD_TV", regul_param=0.002, iterations=8)),
+    "fista_os7_roftv": ("FISTA", dict(os_number=7), {}, dict(iterations=2, lipschitz_const="L_os7"),
+                        dict(method="ROF_TV", regul_param=0.002, iterations=8, time_marching_step=0.002)),
+    "fista_os4_pdtv_half_aniso": ("FISTA", dict(os_number=4), {}, dict(iterations=2, lipschitz_const="L_os4"),
+                                  dict(method="PD_TV", regul_param=0.002, iterations=6, methodTV=1, half_precision=True)),
+    "fista_pwls_os4": ("FISTA", dict(os_number=4), dict(data_fidelity="PWLS"), dict(iterations=3, lipschitz_const="L_os4"), None),
+    "fista_pad_os4": ("FISTA", dict(os_number=4, pad=4), {}, dict(iterations=3, lipschitz_const="L_pad_os4",
+                                                                  recon_mask_radius=2.0), None),
+    "admm_plain": ("ADMM", {}, {}, dict(iterations=5, lipschitz_const="L_full"), None),
+    "admm_pdtv": ("ADMM", {}, {}, dict(iterations=4, lipschitz_const="L_full", ADMM_rho_const=2.0, ADMM_relax_par=1.5,
+                                       nonnegativity=True), dict(method="PD_TV", regul_param=0.004, iterations=8)),
+    "admm_os4_roftv": ("ADMM", dict(os_number=4), {}, dict(iterations=4, lipschitz_const="L_os4"),
+                       dict(method="ROF_TV", regul_param=0.004, iterations=8, time_marching_step=0.002)),
+    "admm_os4_pwls": ("ADMM", dict(os_number=4), dict(data_fidelity="PWLS"),
+                      dict(iterations=3, lipschitz_const="L_os4", recon_mask_radius=0.9), None),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_against_reference_python_loops(outer, geom, name):
+    method, mk, dk, ak, reg = CASES[name]
+    rt = make(geom, **mk)
+    alg = dict(ak)
+    alg["lipschitz_const"] = float(outer[alg["lipschitz_const"]])
+    reg_in = None if reg is None else dict(reg)
+    rec = getattr(rt, method)(data_dict(geom, **dk), alg, reg_in)
+    got = host(rec)
+    assert got.dtype == np.float32
+    assert got.shape == (geom["nz"], geom["n"], geom["n"])
+    assert rel(got, outer[name]) < TOL, rel(got, outer[name])
+    if reg is not None and method == "ADMM":
+        assert reg_in["regul_param"] == reg["regul_param"], "caller's dictionary must not be rewritten"
+
+
+def test_kl_warm_start_axis_swap_cor_2d(outer, geom):
+    L = float(outer["L_full"])
+    # KL fidelity with a warm start (pre-log data)
+    rt = make(geom)
+    d = {"projection_data": torch.from_numpy(outer["raw_kl"]).cuda(),
+         "data_axes_labels_order": ["detY", "angles", "detX"], "data_fidelity": "KL"}
+    x0 = torch.from_numpy(outer["x0_kl"]).cuda()
+    rec = rt.FISTA(d, {"iterations": 3, "lipschitz_const": L, "initialise": x0, "nonnegativity": True})
+    assert rel(host(rec), outer["fista_kl"]) < TOL
+    assert np.array_equal(host(x0), outer["x0_kl"]), "the warm-start array must not be modified"
+    # warm start from a previous reconstruction
+    rec = make(geom).FISTA(data_dict(geom), {"iterations": 2, "lipschitz_const": L,
+                                             "initialise": torch.from_numpy(outer["fista_plain"]).cuda()})
+    assert rel(host(rec), outer["fista_warm"]) < TOL
+    # data given as [angles, detY, detX] + centre-of-rotation offset (numpy input is accepted too)
+    d = {"projection_data": np.ascontiguousarray(np.swapaxes(geom["sino"], 0, 1)),
+         "data_axes_labels_order": ["angles", "detY", "detX"]}
+    rec = make(geom, cor=1.5).FISTA(d, {"iterations": 4, "lipschitz_const": L})
+    assert rel(host(rec), outer["fista_perm_cor"]) < TOL
+    assert d["data_axes_labels_order"] is None and d["data_fidelity"] == "LS"  # dicts are populated in place
+    # 2D input [angles, detX] -> output [1, N, N]
+    d2 = {"projection_data": torch.from_numpy(np.ascontiguousarray(geom["sino"][1])).cuda(),
+          "data_axes_labels_order": ["angles", "detX"]}
+    rec = make(geom, detV=None, os_number=4).FISTA(d2, {"iterations": 3, "lipschitz_const": float(outer["L_os4"])},
+                                                   {"method": "PD_TV", "regul_param": 0.002, "iterations": 8})
+    assert tuple(rec.shape) == (1, geom["n"], geom["n"])
+    assert rel(host(rec), outer["fista_2d_os4_pdtv"]) < TOL
+
+
+def test_power_method_against_reference(outer, geom):
+    for key, os_n in (("L_full", None), ("L_os4", 4), ("L_os7", 7)):
+        rt = make(geom, os_number=os_n)
+        rt.power_seed = 1
+        lc = rt.powermethod({"projection_data": None})
+        assert isinstance(lc, float)
+        np.testing.assert_allclose(lc, float(outer[key]), rtol=2e-5)
+    rt = make(geom, os_number=4, pad=4)
+    np.testing.assert_allclose(rt.powermethod({"projection_data": None}), float(outer["L_pad_os4"]), rtol=2e-5)
+
+
+def test_lipschitz_computed_when_absent_and_bad_initialise(geom, capsys):
+    rt = make(geom, os_number=4)
+    rec = rt.FISTA(data_dict(geom), {"iterations": 1, "initialise": torch.zeros((2, 3, 4), device="cuda")})
+    assert "incorrect dimensions" in capsys.readouterr().out
+    assert tuple(rec.shape) == (geom["nz"], geom["n"], geom["n"])
+
+
+def test_errors_match_reference(geom):
+    from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    rt = make(geom)
+    with pytest.raises(NameError):
+        rt.FISTA({"projection_data": None})
+    with pytest.raises(ValueError):
+        rt.FISTA(data_dict(geom, data_fidelity="L2"))
+    with pytest.raises(ValueError):
+        rt.FISTA(data_dict(geom), {"nonnegativity": "yes"})
+    with pytest.raises(NameError):
+        make(geom, os_number=3).SIRT(data_dict(geom))
+    with pytest.raises(ValueError):
+        RecToolsIRCuPy(0, 0, 4, 0.0, geom["angles"], 16)
+    with pytest.raises(ValueError):
+        RecToolsIRCuPy(16, 0, 4, 0.0, np.zeros((2, 2)), 16)
+    with pytest.raises(ValueError):
+        RecToolsIRCuPy(16, 0, 4, 0.0, geom["angles"], 16, OS_number=0)
+
+
+def test_simple_iterative_methods_vs_oracle(oracle, geom):
+    """Landweber / SIRT / CGLS loops (methodsIR_CuPy.py:128-309 of the reference) on the HIP operators vs the same
+    loops written with the oracle's operators."""
+    sino, angles, nz, n = geom["sino"], geom["angles"], geom["nz"], geom["n"]
+    P = oracle.Projector(nz, n, n, angles)
+    # Landweber
+    x = np.zeros((nz, n, n), np.float32)
+    for _ in range(5):
+        x = x - np.float32(1e-3) * P.bp(P.fp(x) - sino)
+    got = host(make(geom).Landweber(data_dict(geom), {"iterations": 5, "tau_step_lanweber": 1e-3, "recon_mask_radius": None}))
+    assert rel(got, x) < TOL
+    # SIRT
+    with np.errstate(divide="ignore"):
+        R = np.nan_to_num(np.float32(1) / P.fp(np.ones((nz, n, n), np.float32)), nan=1.0, posinf=1.0, neginf=1.0)
+        Cm = np.nan_to_num(np.float32(1) / P.bp(np.ones_like(sino)), nan=1.0, posinf=1.0, neginf=1.0)
+    x = np.ones((nz, n, n), np.float32)
+    for _ in range(4):
+        x = x + Cm * P.bp(R * (sino - P.fp(x)))
+    got = host(make(geom).SIRT(data_dict(geom), {"iterations": 4, "recon_mask_radius": None}))
+    assert rel(got, x) < TOL
+    # CGLS
+    x = np.zeros(nz * n * n, np.float32)
+    d = P.bp(sino).ravel()
+    normr2 = np.inner(d, d)
+    r = sino.ravel().copy()
+    for _ in range(4):
+        Ad = P.fp(d.reshape(nz, n, n)).ravel()
+        alpha = normr2 / np.inner(Ad, Ad)
+        x = x + alpha * d
+        r = r - alpha * Ad
+        s = P.bp(r.reshape(sino.shape)).ravel()
+        normr2_new = np.inner(s, s)
+        d = s + (normr2_new / normr2) * d
+        normr2 = normr2_new
+    got = host(make(geom).CGLS(data_dict(geom), {"iterations": 4, "recon_mask_radius": None}))
+    assert rel(got, x.reshape(nz, n, n)) < 1e-4  # inner products accumulate in a different order
+
+
+def test_dir_forwproj_backproj(oracle, geom):
+    from tomobar_amd.methodsDIR_CuPy import RecToolsDIRCuPy
+    rt = RecToolsDIRCuPy(geom["n"], 0, geom["nz"], 0.0, geom["angles"], geom["n"], device_projector=0)
+    P = oracle.Projector(geom["nz"], geom["n"], geom["n"], geom["angles"])
+    vol = np.random.default_rng(0).random((geom["nz"], geom["n"], geom["n"])).astype(np.float32)
+    assert rel(host(rt.FORWPROJ(torch.from_numpy(vol).cuda())), P.fp(vol)) < 1e-6
+    swapped = torch.from_numpy(geom["sino"]).cuda().permute(1, 0, 2)  # a strided [angles, detY, detX] view
+    got = rt.BACKPROJ(swapped, data_axes_labels_order=["angles", "detY", "detX"])
+    assert rel(host(got), P.bp(geom["sino"])) < 1e-6
