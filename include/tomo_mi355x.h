@@ -193,6 +193,12 @@ int tomo_roftv_iter_slab(int device, const float *in_dev, const float *u_in_dev,
 /* kernel-variant selector for A/B measurement: name in {"bp","fp","pdtv","roftv"}; variant 0 = default */
 int tomo_set_variant(const char *kernel, int variant);
 
+/* In-library kernel timing for bench.py's roofline object: while enabled, every launch group of a kernel class
+ * ("bp","fp","pdtv","roftv") is bracketed by HIP events recorded ON THE LAUNCH STREAM.  tomo_profile_read
+ * synchronises those events and returns the number of kernel launches and their summed duration. */
+int tomo_profile_enable(int on);
+int tomo_profile_read(const char *kernel, long long *launches, double *total_ms);
+
 #ifdef __cplusplus
 }
 #endif

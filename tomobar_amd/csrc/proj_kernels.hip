@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void bp_tiled_kernel(BpArgs a)
 template <int EPI>
 int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
 {
+    tomo_prof_scope prof(PROF_BP, st, 1);
     if (g_variant_bp == 1) {
         dim3 grid(ceil_div(a.n, 64), ceil_div(a.n, 4), ceil_div(a.nz, 4));
         if (lerp8) bp_direct_kernel<EPI, true><<<grid, 256, 0, st>>>(a);
@@ -350,6 +351,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
     a.nz = ctx->nz; a.n = ctx->n; a.nu = ctx->nu; a.na = s.size; a.na_full = ctx->na;
     a.out = out; a.b = b; a.w = w; a.fidelity = fidelity; a.gathered = gathered;
     dim3 grid(ceil_div(ctx->nu, 256), s.size, ceil_div(ctx->nz, 4));
+    tomo_prof_scope prof(PROF_FP, st, 1);
     const bool l8 = (ctx->flags & TOMO_FLAG_LERP8) != 0;
     if (b) {
         if (l8) fp_march_kernel<true, true><<<grid, 256, 0, st>>>(a);

@@ -236,3 +236,66 @@ extern "C" int tomo_release_scratch(int device)
     }
     return TOMO_OK;
 }
+
+// ---- launch-group timing ------------------------------------------------------------------------
+struct prof_rec { hipEvent_t a, b; long long launches; };
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<prof_rec> g_prof[PROF_CLASSES];
+
+tomo_prof_scope::tomo_prof_scope(int cls_, hipStream_t st_, int launches_) : cls(cls_), st(st_), launches(launches_), rec(nullptr)
+{
+    if (!g_prof_on) return;
+    prof_rec *r = new prof_rec();
+    r->launches = launches;
+    if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return; }
+    (void)hipEventRecord(r->a, st);
+    rec = r;
+}
+
+tomo_prof_scope::~tomo_prof_scope()
+{
+    if (!rec) return;
+    prof_rec *r = (prof_rec *)rec;
+    (void)hipEventRecord(r->b, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof[cls].push_back(*r);
+    delete r;
+}
+
+static void prof_clear()
+{
+    for (auto &v : g_prof) {
+        for (auto &r : v) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        v.clear();
+    }
+}
+
+extern "C" int tomo_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_clear();
+    g_prof_on = on != 0;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_profile_read(const char *kernel, long long *launches, double *total_ms)
+{
+    TOMO_REQUIRE(kernel && launches && total_ms, "NULL argument");
+    std::string k(kernel);
+    int cls = k == "bp" ? PROF_BP : k == "fp" ? PROF_FP : k == "pdtv" ? PROF_PDTV : k == "roftv" ? PROF_ROFTV : -1;
+    TOMO_REQUIRE(cls >= 0, "unknown kernel '%s'", kernel);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    long long n = 0;
+    double ms = 0.0;
+    for (auto &r : g_prof[cls]) {
+        TOMO_HIP(hipEventSynchronize(r.b));
+        float t = 0.0f;
+        TOMO_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        ms += t;
+        n += r.launches;
+    }
+    *launches = n;
+    *total_ms = ms;
+    return TOMO_OK;
+}

@@ -62,3 +62,14 @@ int tomo_arena_get(int device, size_t bytes, void **out);
 extern int g_variant_bp, g_variant_fp, g_variant_pdtv, g_variant_roftv;
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- optional event timing of launch groups (tomo_profile_enable / tomo_profile_read)
+enum { PROF_BP = 0, PROF_FP = 1, PROF_PDTV = 2, PROF_ROFTV = 3, PROF_CLASSES = 4 };
+struct tomo_prof_scope {
+    int cls;
+    hipStream_t st;
+    int launches;
+    void *rec;  // opaque
+    tomo_prof_scope(int cls, hipStream_t st, int launches);
+    ~tomo_prof_scope();
+};

@@ -431,6 +431,7 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
     // U_arrays[0] = data.copy() is not materialised: iteration 0 reads the caller's buffer directly;
     // duals start at zero (regularisersCuPy.py:221-223); every U / P output buffer is fully overwritten
     for (int c = 0; c < nd; ++c) TOMO_HIP(hipMemsetAsync(P[0][c], 0, pb, st));
+    tomo_prof_scope prof(PROF_PDTV, st, iters);
     for (int it = 0; it < iters; ++it) {
         const int ib = it & 1, ob = ib ^ 1;
         PdArgs a;
@@ -491,6 +492,7 @@ extern "C" int tomo_roftv(int device, const float *in_dev, float *out_dev, int d
     if (rc != TOMO_OK) return rc;
     const size_t ub = align_up(nvox * sizeof(float), 256);
     float *U[2] = {(float *)base, (float *)((char *)base + ub)};
+    tomo_prof_scope prof(PROF_ROFTV, st, iters);
     for (int it = 0; it < iters; ++it) {
         RofArgs a;
         a.in = in_dev;
