@@ -176,7 +176,7 @@ TV_SHAPES = [(6, 9, 13), (1, 20, 17), (12, 1, 70), (10, 11, 1), (8, 8, 8), (3, 5
 
 
 @pytest.mark.parametrize("shape", TV_SHAPES)
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_pdtv_vs_oracle(oracle, ops, shape, variant):
     from tomobar_amd.regularisersCuPy import PD_TV_cupy
     ops.set_variant("pdtv", variant)

@@ -323,3 +323,45 @@ extern "C" int tomo_permute3(const float *in, float *out, int d0, int d1, int d2
     TOMO_LAUNCH_CHECK();
     return TOMO_OK;
 }
+
+// ---- diagnostics: N-stream streaming kernel (calibrates the achievable HBM rate for a kernel's read/write mix)
+namespace {
+struct StreamArgs { const float *in[8]; float *out[8]; int nin, nout; size_t n; };
+template <int VEC>
+__global__ __launch_bounds__(256) void diag_stream_kernel(StreamArgs a)
+{
+    const size_t nv = a.n / VEC;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+        for (int k = 0; k < a.nin; ++k) {
+            if (VEC == 4) {
+                float4 t = reinterpret_cast<const float4 *>(a.in[k])[i];
+                acc[0] += t.x; acc[1 % VEC] += t.y; acc[2 % VEC] += t.z; acc[3 % VEC] += t.w;
+            } else {
+                acc[0] += a.in[k][i];
+            }
+        }
+        for (int k = 0; k < a.nout; ++k) {
+            if (VEC == 4) reinterpret_cast<float4 *>(a.out[k])[i] = make_float4(acc[0] + k, acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+            else a.out[k][i] = acc[0] + k;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int tomo_diag_stream(const float *const *in_dev, int nin, float *const *out_dev, int nout, size_t count,
+                                int vec, int grid, void *stream)
+{
+    TOMO_REQUIRE(nin >= 0 && nin <= 8 && nout >= 1 && nout <= 8, "at most 8 input and 8 output streams");
+    StreamArgs a;
+    for (int k = 0; k < 8; ++k) { a.in[k] = k < nin ? in_dev[k] : nullptr; a.out[k] = k < nout ? out_dev[k] : nullptr; }
+    a.nin = nin; a.nout = nout; a.n = count;
+    if (grid <= 0) grid = EW_MAX_GRID;
+    if (vec == 4) diag_stream_kernel<4><<<grid, 256, 0, as_stream(stream)>>>(a);
+    else diag_stream_kernel<1><<<grid, 256, 0, as_stream(stream)>>>(a);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}

@@ -239,6 +239,8 @@ __global__ __launch_bounds__(256) void pd_zmarch_kernel(PdArgs a)
     }
 }
 
+#include "pd_zmarch2.inl"
+
 template <typename T, int ND, bool NONNEG, bool ANISO>
 int pd_launch(const PdArgs &a0, int variant, hipStream_t st)
 {
@@ -248,6 +250,13 @@ int pd_launch(const PdArgs &a0, int variant, hipStream_t st)
     if (variant == 1) {
         dim3 grid(ceil_div(a.dx, 256), a.dy, nout);
         pd_pervoxel_kernel<T, ND, NONNEG, ANISO><<<grid, 256, 0, st>>>(a);
+    } else if (variant == 0 || (variant >= 3 && variant <= 6)) {
+        int rc = (variant == 0)   ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 4, false>(a, st)
+                 : (variant == 3) ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 8, false>(a, st)
+                 : (variant == 4) ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 2, false>(a, st)
+                 : (variant == 5) ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 4, true>(a, st)
+                                  : pd_zmarch2_launch<T, ND, NONNEG, ANISO, 8, true>(a, st);
+        if (rc != TOMO_OK) return rc;
     } else {
         constexpr int RY = 4;
         // enough z-chunks to fill the chip (>= ~8 waves per SIMD) but long enough to amortise the warm-up plane
@@ -385,13 +394,28 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ C-ABI
+// Scratch arrays of equal power-of-two size laid end to end put the same voxel of every array on the same HBM
+// channel and bank; the 9-10 concurrent streams of a TV iteration then thrash DRAM rows.  Each array is therefore
+// started `tv_skew()` bytes further than the plain packing would (k-th array: k * skew).
+static size_t tv_skew()
+{
+    static long skew = -1;
+    if (skew < 0) {
+        const char *e = getenv("TOMO_TV_SKEW");
+        skew = e ? atol(e) : 0;
+        if (skew < 0) skew = 0;
+        skew = (skew + 255) / 256 * 256;
+    }
+    return (size_t)skew;
+}
+
 extern "C" size_t tomo_pdtv_scratch_bytes(int dx, int dy, int dz, int nd, int half)
 {
     if (nd == 2) dz = 1;
     const size_t nvox = (size_t)dx * dy * dz;
     const size_t ub = align_up(nvox * sizeof(float), 256);
     const size_t pb = align_up(nvox * (half ? 2 : 4), 256);
-    return 2 * ub + 2 * (size_t)nd * pb;
+    return 2 * ub + 2 * (size_t)nd * pb + 8 * tv_skew();
 }
 
 extern "C" size_t tomo_roftv_scratch_bytes(int dx, int dy, int dz, int nd)
@@ -424,10 +448,11 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
     char *cur = (char *)base;
     float *U[2];
     void *P[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-    U[0] = (float *)cur; cur += ub;
-    U[1] = (float *)cur; cur += ub;
+    const size_t skew = tv_skew();
+    U[0] = (float *)cur; cur += ub + skew;
+    U[1] = (float *)cur; cur += ub + skew;
     for (int b = 0; b < 2; ++b)
-        for (int c = 0; c < nd; ++c) { P[b][c] = cur; cur += pb; }
+        for (int c = 0; c < nd; ++c) { P[b][c] = cur; cur += pb + skew; }
     // U_arrays[0] = data.copy() is not materialised: iteration 0 reads the caller's buffer directly;
     // duals start at zero (regularisersCuPy.py:221-223); every U / P output buffer is fully overwritten
     for (int c = 0; c < nd; ++c) TOMO_HIP(hipMemsetAsync(P[0][c], 0, pb, st));

@@ -1,0 +1,48 @@
+"""Small fixed workloads for rocprofv3 --pmc passes (one kernel class per invocation, few launches).
+usage: python tools/pmc_probe.py <what> [N] [NZ] [NA]   what in {pdtv0,pdtv1,pdtv0h,roftv,bp0,bp1,fp,momentum}"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from tomobar_amd import ops
+from tomobar_amd.projector import HipTools3D
+from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
+
+what = sys.argv[1]
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+NZ = int(sys.argv[3]) if len(sys.argv) > 3 else N
+NA = int(sys.argv[4]) if len(sys.argv) > 4 else 75
+vol = torch.rand((NZ, N, N), device="cuda")
+out = torch.empty_like(vol)
+if what.startswith("pdtv"):
+    ops.set_variant("pdtv", int(what[4]))
+    PD_TV_cupy(vol, 0.01, 4, 0, 1, 12.0, 0, what.endswith("h"), out=out)
+elif what == "roftv":
+    ROF_TV_cupy(vol, 0.01, 4, 0.001, 0, False, out=out)
+elif what.startswith("stream"):   # stream<nin><nout>[v] e.g. stream54 (dword) / stream54v (float4)
+    import ctypes as C
+    from tomobar_amd import _lib
+    lib = _lib.lib()
+    lib.tomo_diag_stream.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    nin, nout = int(what[6]), int(what[7])
+    ins = [torch.rand_like(vol) for _ in range(nin)]
+    outs = [torch.empty_like(vol) for _ in range(nout)]
+    pi = (C.c_void_p * 8)(*[t.data_ptr() for t in ins])
+    po = (C.c_void_p * 8)(*[t.data_ptr() for t in outs])
+    for _ in range(3):
+        lib.tomo_diag_stream(pi, nin, po, nout, vol.numel(), 4 if what.endswith("v") else 1, 2048, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+elif what == "momentum":
+    for _ in range(4):
+        ops.momentum(vol, out, out, 0.5)
+else:
+    H = HipTools3D(N, 0, NZ, np.linspace(0, np.pi, NA, endpoint=False), 0.0, N, "gpu", 0, None)
+    sino = torch.rand((NZ, NA, N), device="cuda")
+    if what.startswith("bp"):
+        ops.set_variant("bp", int(what[2]))
+        for _ in range(3):
+            H.backward(sino, None, out=out)
+    else:
+        for _ in range(2):
+            H.forward(vol, None, out=sino)
+torch.cuda.synchronize()
