@@ -79,9 +79,11 @@ def test_backprojection_vs_oracle(oracle, ops, g, variant):
         assert np.array_equal(got, want), f"BP not bit-identical: max abs {np.abs(got - want).max()}"
 
 
-@pytest.mark.parametrize("g", GEOMS)
-def test_forward_projection_vs_oracle(oracle, ops, g):
+@pytest.mark.parametrize("g", GEOMS + [(4, 300, 520, 40, 3.0, 1), (5, 64, 700, 13, 0.0, 1)])
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_forward_projection_vs_oracle(oracle, ops, g, variant):
     P, H = make_pair(oracle, g)
+    ops.set_variant("fp", variant)
     rng = np.random.default_rng(2)
     vol = rng.standard_normal((P.nz, P.n, P.n)).astype(np.float32)
     subsets = [None] if P.os_number == 1 else list(range(P.os_number))
@@ -176,7 +178,7 @@ TV_SHAPES = [(6, 9, 13), (1, 20, 17), (12, 1, 70), (10, 11, 1), (8, 8, 8), (3, 5
 
 
 @pytest.mark.parametrize("shape", TV_SHAPES)
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 def test_pdtv_vs_oracle(oracle, ops, shape, variant):
     from tomobar_amd.regularisersCuPy import PD_TV_cupy
     ops.set_variant("pdtv", variant)

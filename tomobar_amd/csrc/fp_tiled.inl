@@ -1,0 +1,334 @@
+// Forward projector, "tiled" variant.  Included inside the anonymous namespace of proj_kernels.hip.
+//
+// A ray-driven Joseph projector re-reads the whole volume once per angle; done naively that is V*Na_s*4 bytes of
+// L2/Infinity-Cache traffic per call (322 GB for 1024^3 x 75 angles).  Here a workgroup owns 256 detector pixels x
+// FP_A angles of ONE stepping class (all of them interpolate along the same, contiguous, in-plane axis) x 4 slices and
+// marches the stepping axis.  For every row of the march the part of that volume row which the 256 x FP_A rays can
+// touch is staged ONCE in LDS (as float4 over the 4 slices, zero outside the volume) and then sampled by all FP_A
+// angles: ~1 byte of staging traffic per ray-step instead of ~6.  Staging is software-pipelined: the global loads of
+// chunk c+1 are in flight (held in registers) while chunk c is sampled from the other LDS buffer; one barrier per
+// chunk.  Each (pixel, angle, slice) accumulator lives in a register and is summed in march order, so the result is
+// bit-identical to the sequential oracle.
+constexpr int FP_A = 8;               // angles per workgroup
+constexpr int FP_M = 8;               // float4 staging items per thread and chunk (register prefetch depth)
+constexpr int FP_MAX_WPITCH = 1024;   // 4 passes of 256 columns
+
+struct FpTiledArgs {
+    const float *src;        // volume with the interpolation axis contiguous ([nz][n][n])
+    const tomo_angle_t *tab; // subset table
+    const int *order;        // subset-local angle indices of this stepping class
+    int n_class;             // angles in the class
+    int nz, n, nu, na, na_full;
+    float *out;
+    const float *b, *w;
+    int fidelity, gathered;
+    int wpitch;              // LDS pitch (float4 units) per staged row, <= 256 * passes <= 1024
+    int nut, ngroups, nzb;   // detector tiles, angle groups, slice quads
+};
+
+// PASSES = ceil(wpitch / 256) column passes per staged row; KC = FP_M / PASSES rows per chunk (compile-time so that the
+// staging index arithmetic is free of integer divisions).
+template <bool LERP8, bool RESID, int PASSES>
+__global__ __launch_bounds__(256) void fp_tiled_kernel(FpTiledArgs a)
+{
+    constexpr int KC = FP_M / PASSES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fp_smem[];
+    const int tile_items = KC * a.wpitch;
+    float4 *tile0 = reinterpret_cast<float4 *>(fp_smem);
+    float4 *tile1 = tile0 + tile_items;
+    int *win_lo = reinterpret_cast<int *>(tile1 + tile_items);  // [n]
+    int *win_wid = win_lo + a.n;                                // [n]
+
+    // XCD-aware numbering: one slice-quad stream per XCD so that its L2 keeps that quad's rows
+    const int per_zb = a.nut * a.ngroups;
+    const int q = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
+    const int zb = (q / per_zb) * 8 + xcd;
+    if (zb >= a.nzb) return;
+    const int rest = q % per_zb;
+    const int ut = rest % a.nut, g = rest / a.nut;
+    const int z0 = zb * 4;
+    const int u0 = ut * 256;
+    const int tid = (int)threadIdx.x;
+    const int iu = u0 + tid;
+    const int n = a.n;
+    const int ng = min(FP_A, a.n_class - g * FP_A);   // angles in this group (uniform)
+    const int *ord = a.order + g * FP_A;
+
+    const float half_n = 0.5f * (float)n - 0.5f, half_u = 0.5f * (float)a.nu - 0.5f;
+    float offs[FP_A], slope[FP_A], acc[FP_A][4];
+#pragma unroll
+    for (int i = 0; i < FP_A; ++i) {
+        const tomo_angle_t t = a.tab[ord[i < ng ? i : 0]];
+        const float s = ((float)iu - half_u) + t.cor;
+        offs[i] = fmaf(s, t.inv, half_n);
+        slope[i] = t.slope;
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz) acc[i][zz] = 0.0f;
+    }
+
+    // ---- window of every march row (the sampling coordinate is monotone in the detector index, so the two ends of
+    //      the detector tile bound it); two zero columns on either side (-2,-1 / n,n+1) absorb rays that miss the volume
+    for (int k = tid; k < n; k += 256) {
+        const float kw = (float)k - half_n;
+        float fmin = 3.0e38f, fmax = -3.0e38f;
+        for (int i = 0; i < ng; ++i) {
+            const tomo_angle_t t = a.tab[ord[i]];
+            const float o0 = fmaf(((float)u0 - half_u) + t.cor, t.inv, half_n);
+            const float o1 = fmaf(((float)(u0 + 255) - half_u) + t.cor, t.inv, half_n);
+            const float f0 = fmaf(kw, t.slope, o0), f1 = fmaf(kw, t.slope, o1);
+            fmin = fminf(fmin, fminf(f0, f1));
+            fmax = fmaxf(fmax, fmaxf(f0, f1));
+        }
+        const int lo = (int)fminf(fmaxf(floorf(fmin), -2.0f), (float)n);
+        const int hi = (int)fminf(fmaxf(floorf(fmax) + 1.0f, -1.0f), (float)(n + 1));
+        win_lo[k] = lo;
+        win_wid[k] = max(hi - lo + 1, 2);
+    }
+    __syncthreads();
+
+    const size_t zstride = (size_t)n * n;
+    // slices beyond nz read slice nz-1 (valid memory) and are zeroed by the select below
+    const float *p0 = a.src + (size_t)z0 * zstride;
+    const float *p1 = a.src + (size_t)min(z0 + 1, a.nz - 1) * zstride;
+    const float *p2 = a.src + (size_t)min(z0 + 2, a.nz - 1) * zstride;
+    const float *p3 = a.src + (size_t)min(z0 + 3, a.nz - 1) * zstride;
+    const unsigned k1 = z0 + 1 < a.nz ? 0xffffffffu : 0u, k2 = z0 + 2 < a.nz ? 0xffffffffu : 0u, k3 = z0 + 3 < a.nz ? 0xffffffffu : 0u;
+
+    float4 pre[FP_M];
+    // branch-free gather of the chunk starting at row k0 into registers: pre[r * PASSES + p] <- (row k0+r, column tid+256p).
+    // Invalid items (outside the window / volume / march) load a clamped address and are zeroed with a bit mask.
+    auto prefetch = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < KC; ++r) {
+            const int k = min(k0 + r, n - 1);
+            const int lo = win_lo[k], wid = (k0 + r < n) ? win_wid[k] : 0;
+            const unsigned rowoff = (unsigned)k * (unsigned)n;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int j = tid + 256 * p;
+                const int x = lo + j;
+                const unsigned mk = (j < wid && x >= 0 && x < n) ? 0xffffffffu : 0u;
+                const unsigned off = rowoff + (unsigned)min(max(x, 0), n - 1);
+                float4 v;
+                v.x = __uint_as_float(__float_as_uint(p0[off]) & mk);
+                v.y = __uint_as_float(__float_as_uint(p1[off]) & (mk & k1));
+                v.z = __uint_as_float(__float_as_uint(p2[off]) & (mk & k2));
+                v.w = __uint_as_float(__float_as_uint(p3[off]) & (mk & k3));
+                pre[r * PASSES + p] = v;
+            }
+        }
+    };
+
+    const int nchunks = (n + KC - 1) / KC;
+    prefetch(0);
+    for (int c = 0; c < nchunks; ++c) {
+        float4 *tile = (c & 1) ? tile1 : tile0;
+#pragma unroll
+        for (int r = 0; r < KC; ++r)
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int j = tid + 256 * p;
+                if (j < a.wpitch) tile[r * a.wpitch + j] = pre[r * PASSES + p];
+            }
+        __syncthreads();  // chunk c staged; every wave is past the sampling of chunk c-1 (other buffer)
+        const int k0 = c * KC;
+        if (c + 1 < nchunks) prefetch(k0 + KC);  // in flight while chunk c is sampled
+#pragma unroll
+        for (int r = 0; r < KC; ++r) {
+            // rows past the end of the march are staged as zeros and sampled with the last row's (valid) coordinates,
+            // so they add exactly nothing and no tail branch is needed
+            const int kr = min(k0 + r, n - 1);
+            const float kw = (float)kr - half_n;
+            const int lo = win_lo[kr];
+            const float4 *trow = tile + r * a.wpitch;
+#pragma unroll
+            for (int i = 0; i < FP_A; ++i) {  // slots >= ng repeat angle 0 (never stored)
+                const float f = fmaf(kw, slope[i], offs[i]);
+                const float fl = floorf(f);
+                const float w = lerp_w<LERP8>(f, fl), omw = 1.0f - w;
+                // rays outside [-2, n] sample the zero columns; clamp in float so the int conversion is safe
+                const int idx = (int)fminf(fmaxf(fl, -2.0f), (float)n) - lo;
+                const float4 s0 = trow[idx], s1 = trow[idx + 1];
+                acc[i][0] = fmaf(omw, s0.x, acc[i][0]); acc[i][0] = fmaf(w, s1.x, acc[i][0]);
+                acc[i][1] = fmaf(omw, s0.y, acc[i][1]); acc[i][1] = fmaf(w, s1.y, acc[i][1]);
+                acc[i][2] = fmaf(omw, s0.z, acc[i][2]); acc[i][2] = fmaf(w, s1.z, acc[i][2]);
+                acc[i][3] = fmaf(omw, s0.w, acc[i][3]); acc[i][3] = fmaf(w, s1.w, acc[i][3]);
+            }
+        }
+    }
+    if (iu >= a.nu) return;
+#pragma unroll
+    for (int i = 0; i < FP_A; ++i) {
+        if (i >= ng) break;
+        const int k_a = ord[i];
+        const tomo_angle_t t = a.tab[k_a];
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz) {
+            const int z = z0 + zz;
+            if (z >= a.nz) break;
+            float val = acc[i][zz] * t.scale;
+            if (RESID) {
+                const size_t gi = ((size_t)z * a.na + k_a) * a.nu + iu;
+                const size_t fi = ((size_t)z * a.na_full + t.src) * a.nu + iu;
+                const float bv = a.b[(a.gathered & TOMO_GATHERED_B) ? gi : fi];
+                if (a.fidelity == TOMO_FID_KL || a.fidelity == TOMO_FID_RATIO) {
+                    const float ax = val < 1e-8f ? 1e-8f : val;
+                    const float qv = bv / ax;
+                    val = (a.fidelity == TOMO_FID_KL) ? 1.0f - qv : qv;
+                } else {
+                    val = val - bv;
+                    if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
+                }
+            }
+            a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
+        }
+    }
+}
+
+// Upper bound (host, same float arithmetic as the kernel) of the staged window width over all groups / tiles / rows.
+// The width is a max of affine functions of the row index minus a min of affine functions, hence convex: its maximum
+// over the march is attained at the first or the last row.
+static int fp_window_bound(const tomo_angle_t *tab, const int *order, int n_class, int n, int nu)
+{
+    const float half_n = 0.5f * (float)n - 0.5f, half_u = 0.5f * (float)nu - 0.5f;
+    int bound = 2;
+    const int nut = ceil_div(nu, 256);
+    for (int g = 0; g * FP_A < n_class; ++g) {
+        const int ng = std::min(FP_A, n_class - g * FP_A);
+        for (int ut = 0; ut < nut; ++ut) {
+            for (int e = 0; e < 2; ++e) {
+                const float kw = (float)(e ? n - 1 : 0) - half_n;
+                float fmin = 3.0e38f, fmax = -3.0e38f;
+                for (int i = 0; i < ng; ++i) {
+                    const tomo_angle_t &t = tab[order[g * FP_A + i]];
+                    const float o0 = std::fmaf(((float)(ut * 256) - half_u) + t.cor, t.inv, half_n);
+                    const float o1 = std::fmaf(((float)(ut * 256 + 255) - half_u) + t.cor, t.inv, half_n);
+                    const float f0 = std::fmaf(kw, t.slope, o0), f1 = std::fmaf(kw, t.slope, o1);
+                    fmin = std::min(fmin, std::min(f0, f1));
+                    fmax = std::max(fmax, std::max(f0, f1));
+                }
+                const int lo = (int)std::min(std::max(std::floor(fmin), -2.0f), (float)n);
+                const int hi = (int)std::min(std::max(std::floor(fmax) + 1.0f, -1.0f), (float)(n + 1));
+                bound = std::max(bound, hi - lo + 1);
+            }
+        }
+    }
+    return std::min(bound + 2, n + 4);
+}
+
+// ---- synchronous (non-pipelined) form: stage kc rows, barrier, sample, barrier.  Small LDS footprint, so many
+//      workgroups per CU hide the staging latency instead of a register prefetch.  Variant 2 (A/B measurement).
+template <bool LERP8, bool RESID>
+__global__ __launch_bounds__(256) void fp_tiled_sync_kernel(FpTiledArgs a, int kc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fp_smem[];
+    float4 *tile = reinterpret_cast<float4 *>(fp_smem);
+    __shared__ int xlo_s[8], wid_s[8];
+    const int per_zb = a.nut * a.ngroups;
+    const int q = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
+    const int zb = (q / per_zb) * 8 + xcd;
+    if (zb >= a.nzb) return;
+    const int rest = q % per_zb;
+    const int ut = rest % a.nut, g = rest / a.nut;
+    const int z0 = zb * 4, u0 = ut * 256, tid = (int)threadIdx.x, iu = u0 + tid, n = a.n;
+    const int ng = min(FP_A, a.n_class - g * FP_A);
+    const int *ord = a.order + g * FP_A;
+    const float half_n = 0.5f * (float)n - 0.5f, half_u = 0.5f * (float)a.nu - 0.5f;
+    float offs[FP_A], slope[FP_A], acc[FP_A][4];
+#pragma unroll
+    for (int i = 0; i < FP_A; ++i) {
+        const tomo_angle_t t = a.tab[ord[i < ng ? i : 0]];
+        offs[i] = fmaf(((float)iu - half_u) + t.cor, t.inv, half_n);
+        slope[i] = t.slope;
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz) acc[i][zz] = 0.0f;
+    }
+    const size_t zstride = (size_t)n * n;
+    const float *p0 = a.src + (size_t)z0 * zstride;
+    const float *p1 = a.src + (size_t)min(z0 + 1, a.nz - 1) * zstride;
+    const float *p2 = a.src + (size_t)min(z0 + 2, a.nz - 1) * zstride;
+    const float *p3 = a.src + (size_t)min(z0 + 3, a.nz - 1) * zstride;
+    const unsigned k1 = z0 + 1 < a.nz ? 0xffffffffu : 0u, k2 = z0 + 2 < a.nz ? 0xffffffffu : 0u, k3 = z0 + 3 < a.nz ? 0xffffffffu : 0u;
+    for (int k0 = 0; k0 < n; k0 += kc) {
+        const int rows = min(kc, n - k0);
+        __syncthreads();
+        if (tid < rows) {
+            const float kw = (float)(k0 + tid) - half_n;
+            float fmin = 3.0e38f, fmax = -3.0e38f;
+            for (int i = 0; i < ng; ++i) {
+                const tomo_angle_t t = a.tab[ord[i]];
+                const float o0 = fmaf(((float)u0 - half_u) + t.cor, t.inv, half_n);
+                const float o1 = fmaf(((float)(u0 + 255) - half_u) + t.cor, t.inv, half_n);
+                const float f0 = fmaf(kw, t.slope, o0), f1 = fmaf(kw, t.slope, o1);
+                fmin = fminf(fmin, fminf(f0, f1));
+                fmax = fmaxf(fmax, fmaxf(f0, f1));
+            }
+            const int lo = (int)fminf(fmaxf(floorf(fmin), -2.0f), (float)n);
+            const int hi = (int)fminf(fmaxf(floorf(fmax) + 1.0f, -1.0f), (float)(n + 1));
+            xlo_s[tid] = lo;
+            wid_s[tid] = max(hi - lo + 1, 2);
+        }
+        __syncthreads();
+        for (int r = 0; r < rows; ++r) {
+            const int lo = xlo_s[r], wid = wid_s[r];
+            const unsigned rowoff = (unsigned)(k0 + r) * (unsigned)n;
+            float4 *trow = tile + (size_t)r * a.wpitch;
+            for (int j = tid; j < wid; j += 256) {
+                const int x = lo + j;
+                const unsigned mk = (x >= 0 && x < n) ? 0xffffffffu : 0u;
+                const unsigned off = rowoff + (unsigned)min(max(x, 0), n - 1);
+                float4 v;
+                v.x = __uint_as_float(__float_as_uint(p0[off]) & mk);
+                v.y = __uint_as_float(__float_as_uint(p1[off]) & (mk & k1));
+                v.z = __uint_as_float(__float_as_uint(p2[off]) & (mk & k2));
+                v.w = __uint_as_float(__float_as_uint(p3[off]) & (mk & k3));
+                trow[j] = v;
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < rows; ++r) {
+            const float kw = (float)(k0 + r) - half_n;
+            const int lo = xlo_s[r];
+            const float4 *trow = tile + (size_t)r * a.wpitch;
+#pragma unroll
+            for (int i = 0; i < FP_A; ++i) {
+                const float f = fmaf(kw, slope[i], offs[i]);
+                const float fl = floorf(f);
+                const float w = lerp_w<LERP8>(f, fl), omw = 1.0f - w;
+                const int idx = (int)fminf(fmaxf(fl, -2.0f), (float)n) - lo;
+                const float4 s0 = trow[idx], s1 = trow[idx + 1];
+                acc[i][0] = fmaf(omw, s0.x, acc[i][0]); acc[i][0] = fmaf(w, s1.x, acc[i][0]);
+                acc[i][1] = fmaf(omw, s0.y, acc[i][1]); acc[i][1] = fmaf(w, s1.y, acc[i][1]);
+                acc[i][2] = fmaf(omw, s0.z, acc[i][2]); acc[i][2] = fmaf(w, s1.z, acc[i][2]);
+                acc[i][3] = fmaf(omw, s0.w, acc[i][3]); acc[i][3] = fmaf(w, s1.w, acc[i][3]);
+            }
+        }
+    }
+    if (iu >= a.nu) return;
+#pragma unroll
+    for (int i = 0; i < FP_A; ++i) {
+        if (i >= ng) break;
+        const int k_a = ord[i];
+        const tomo_angle_t t = a.tab[k_a];
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz) {
+            const int z = z0 + zz;
+            if (z >= a.nz) break;
+            float val = acc[i][zz] * t.scale;
+            if (RESID) {
+                const size_t gi = ((size_t)z * a.na + k_a) * a.nu + iu;
+                const size_t fi = ((size_t)z * a.na_full + t.src) * a.nu + iu;
+                const float bv = a.b[(a.gathered & TOMO_GATHERED_B) ? gi : fi];
+                if (a.fidelity == TOMO_FID_KL || a.fidelity == TOMO_FID_RATIO) {
+                    const float ax = val < 1e-8f ? 1e-8f : val;
+                    const float qv = bv / ax;
+                    val = (a.fidelity == TOMO_FID_KL) ? 1.0f - qv : qv;
+                } else {
+                    val = val - bv;
+                    if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
+                }
+            }
+            a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
+        }
+    }
+}

@@ -20,6 +20,9 @@
 // No MFMA: there is no dense contraction on this path.
 #include "tomo_common.h"
 
+#include <algorithm>
+#include <cmath>
+
 namespace {
 
 // ------------------------------------------------------------------------------------------ shared pieces
@@ -322,13 +325,15 @@ __global__ __launch_bounds__(256) void fp_march_kernel(FpArgs a)
     }
 }
 
+#include "fp_tiled.inl"
+
 int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const float *w, int gathered, int fidelity,
            float *out, void *stream)
 {
     TOMO_REQUIRE(ctx != nullptr, "ctx is NULL");
     TOMO_REQUIRE(vol != nullptr && out != nullptr, "NULL data pointer");
     TOMO_REQUIRE(subset < ctx->os, "subset %d out of range (OS_number %d)", subset, ctx->os);
-    const tomo_subset &s = (subset < 0 || ctx->os == 1) ? ctx->subsets[0] : ctx->subsets[1 + subset];
+    tomo_subset &s = (subset < 0 || ctx->os == 1) ? ctx->subsets[0] : ctx->subsets[1 + subset];
     if (s.size == 0) return TOMO_OK;
     TOMO_HIP(hipSetDevice(ctx->device));
     hipStream_t st = as_stream(stream);
@@ -353,6 +358,70 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
     dim3 grid(ceil_div(ctx->nu, 256), s.size, ceil_div(ctx->nz, 4));
     tomo_prof_scope prof(PROF_FP, st, 1);
     const bool l8 = (ctx->flags & TOMO_FLAG_LERP8) != 0;
+    // tiled variant unless a class's LDS window would not fit (very wide angular spread on a very wide volume)
+    bool tiled = (g_variant_fp != 1);
+    if (tiled) {
+        size_t off = s.table_offset;
+        for (int c = 0; c < 2; ++c) {
+            if (s.n_class[c] > 0 && s.wbound[c] < 0)
+                s.wbound[c] = fp_window_bound(ctx->host_table.data() + s.table_offset, ctx->host_fp_order.data() + off,
+                                              s.n_class[c], ctx->n, ctx->nu);
+            if (s.n_class[c] > 0 && s.wbound[c] > 4000) tiled = false;  // one staged row must fit in 64 KiB of LDS
+            off += s.n_class[c];
+        }
+    }
+    if (tiled) {
+        size_t order_off = s.table_offset;
+        for (int c = 0; c < 2; ++c) {  // one launch per stepping class (class 1 reads the transposed copy)
+            const int nc = s.n_class[c];
+            if (nc > 0) {
+                FpTiledArgs t;
+                t.src = c ? a.volT : a.vol;
+                t.tab = a.tab;
+                t.order = ctx->dev_fp_order + order_off;
+                t.n_class = nc;
+                t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
+                t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
+                t.wpitch = s.wbound[c];
+                const int passes = ceil_div(t.wpitch, 256);           // 1..4
+                const int kc = FP_M / (passes == 3 ? 4 : passes);      // template instances: 1, 2, 4 passes
+                const size_t smem = (size_t)2 * kc * t.wpitch * 16 + (size_t)a.n * 8;
+                t.nut = ceil_div(a.nu, 256);
+                t.ngroups = ceil_div(nc, FP_A);
+                t.nzb = ceil_div(a.nz, 4);
+                const long blocks = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
+                TOMO_REQUIRE(blocks <= 0x7fffffffL, "problem too large for one FP launch");
+                // Narrow windows (dense angle sets: <= 2 column passes) run the register-prefetch pipeline; wide
+                // windows (ordered subsets spread the angles of a group) run the synchronous form, whose small LDS
+                // footprint lets many workgroups per CU hide the staging latency.  Measured on MI355X:
+                // 512^3 x 360 angles 8.4 ms (pipelined) vs 10.0 (sync); 1024^3 x 75 angles 22 ms (sync).
+                if (g_variant_fp == 2 || t.wpitch > 512) {
+                    static const int lds_budget = getenv("TOMO_FP_LDS") ? atoi(getenv("TOMO_FP_LDS")) : 24000;
+                    const int kcs = std::max(1, std::min(8, lds_budget / (t.wpitch * 16)));
+                    const size_t sm = (size_t)kcs * t.wpitch * 16;
+                    if (b) { if (l8) fp_tiled_sync_kernel<true, true><<<(unsigned)blocks, 256, sm, st>>>(t, kcs);
+                             else fp_tiled_sync_kernel<false, true><<<(unsigned)blocks, 256, sm, st>>>(t, kcs); }
+                    else   { if (l8) fp_tiled_sync_kernel<true, false><<<(unsigned)blocks, 256, sm, st>>>(t, kcs);
+                             else fp_tiled_sync_kernel<false, false><<<(unsigned)blocks, 256, sm, st>>>(t, kcs); }
+                    TOMO_LAUNCH_CHECK();
+                    order_off += nc;
+                    continue;
+                }
+#define FP_TILED_LAUNCH(L8, RES)                                                                          \
+    do {                                                                                                  \
+        if (passes == 1) fp_tiled_kernel<L8, RES, 1><<<(unsigned)blocks, 256, smem, st>>>(t);             \
+        else if (passes == 2) fp_tiled_kernel<L8, RES, 2><<<(unsigned)blocks, 256, smem, st>>>(t);        \
+        else fp_tiled_kernel<L8, RES, 4><<<(unsigned)blocks, 256, smem, st>>>(t);                         \
+    } while (0)
+                if (b) { if (l8) FP_TILED_LAUNCH(true, true); else FP_TILED_LAUNCH(false, true); }
+                else   { if (l8) FP_TILED_LAUNCH(true, false); else FP_TILED_LAUNCH(false, false); }
+#undef FP_TILED_LAUNCH
+                TOMO_LAUNCH_CHECK();
+            }
+            order_off += nc;
+        }
+        return TOMO_OK;
+    }
     if (b) {
         if (l8) fp_march_kernel<true, true><<<grid, 256, 0, st>>>(a);
         else fp_march_kernel<false, true><<<grid, 256, 0, st>>>(a);

@@ -1,6 +1,7 @@
 // Context, geometry tables, error reporting and scratch arenas of libtomo_mi355x.so.
 #include "tomo_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -112,6 +113,16 @@ extern "C" int tomo_ctx_create(int device, int nz, int n, int nu, int na, const 
             ctx->host_table.push_back(make_angle(angles_host[a], cor_of((int)a), (int)a));
             s.n_dirx += ctx->host_table.back().dirx;
         }
+        // FP order table: class 0 (y-stepping) then class 1 (x-stepping), each sorted by the march slope so that the
+        // angles one workgroup handles together sample neighbouring parts of every volume row
+        const tomo_angle_t *tab = ctx->host_table.data() + s.table_offset;
+        std::vector<int> order[2];
+        for (int i = 0; i < s.size; ++i) order[tab[i].dirx].push_back(i);
+        for (int c = 0; c < 2; ++c) {
+            std::stable_sort(order[c].begin(), order[c].end(), [&](int p, int q) { return tab[p].slope < tab[q].slope; });
+            s.n_class[c] = (int)order[c].size();
+            ctx->host_fp_order.insert(ctx->host_fp_order.end(), order[c].begin(), order[c].end());
+        }
         ctx->subsets.push_back(s);
     };
     std::vector<int64_t> all(na);
@@ -137,7 +148,15 @@ extern "C" int tomo_ctx_create(int device, int nz, int n, int nu, int na, const 
     hipError_t e = hipMalloc((void **)&ctx->dev_table, bytes > 0 ? bytes : sizeof(tomo_angle_t));
     if (e == hipSuccess && bytes)
         e = hipMemcpy(ctx->dev_table, ctx->host_table.data(), bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const size_t ob = ctx->host_fp_order.size() * sizeof(int);
+        e = hipMalloc((void **)&ctx->dev_fp_order, ob > 0 ? ob : sizeof(int));
+        if (e == hipSuccess && ob)
+            e = hipMemcpy(ctx->dev_fp_order, ctx->host_fp_order.data(), ob, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
+        if (ctx->dev_table) (void)hipFree(ctx->dev_table);
+        if (ctx->dev_fp_order) (void)hipFree(ctx->dev_fp_order);
         delete ctx;
         return tomo_fail(TOMO_E_RUNTIME, "angle table upload failed: %s", hipGetErrorString(e));
     }
@@ -150,6 +169,7 @@ extern "C" int tomo_ctx_destroy(tomo_ctx *ctx)
     if (!ctx) return TOMO_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->dev_table) (void)hipFree(ctx->dev_table);
+    if (ctx->dev_fp_order) (void)hipFree(ctx->dev_fp_order);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     delete ctx;
     return TOMO_OK;

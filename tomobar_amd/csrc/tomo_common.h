@@ -36,8 +36,12 @@ int tomo_fail(int code, const char *fmt, ...);
 
 struct tomo_subset {
     int size = 0;             // number of angles
-    size_t table_offset = 0;  // element offset into the device angle table
+    size_t table_offset = 0;  // element offset into the device angle table (and into the FP order table)
     int n_dirx = 0;           // how many angles step along x (FP)
+    // FP stepping classes: the order table lists the subset-local indices of the y-stepping angles (class 0)
+    // followed by the x-stepping ones (class 1), each sorted by angle; wbound = cached LDS window bound (-1 = unset)
+    int n_class[2] = {0, 0};
+    int wbound[2] = {-1, -1};
 };
 
 struct tomo_ctx {
@@ -49,6 +53,8 @@ struct tomo_ctx {
     std::vector<tomo_angle_t> host_table;     // full set followed by every subset
     std::vector<tomo_subset> subsets;         // index 0 = full set, 1 + s = subset s
     tomo_angle_t *dev_table = nullptr;
+    std::vector<int> host_fp_order;           // same indexing as host_table
+    int *dev_fp_order = nullptr;
     void *scratch = nullptr;                  // grow-only (FP: in-plane transposed volume)
     size_t scratch_bytes = 0;
 };

@@ -250,12 +250,13 @@ int pd_launch(const PdArgs &a0, int variant, hipStream_t st)
     if (variant == 1) {
         dim3 grid(ceil_div(a.dx, 256), a.dy, nout);
         pd_pervoxel_kernel<T, ND, NONNEG, ANISO><<<grid, 256, 0, st>>>(a);
-    } else if (variant == 0 || (variant >= 3 && variant <= 6)) {
-        int rc = (variant == 0)   ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 4, false>(a, st)
-                 : (variant == 3) ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 8, false>(a, st)
-                 : (variant == 4) ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 2, false>(a, st)
-                 : (variant == 5) ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 4, true>(a, st)
-                                  : pd_zmarch2_launch<T, ND, NONNEG, ANISO, 8, true>(a, st);
+    } else if (variant == 0 || (variant >= 3 && variant <= 5)) {
+        // measured on MI355X, 1024^3 f32 duals (profiles/r1_pdtv_variants.txt): 4x2 waves x 8 rows, lockstep = 8.6 ms;
+        // 4x4 waves x 4 rows = 9.2 ms; 4x1 x 8 rows = 8.7 ms; unsynchronised waves (1x4, 4 rows) = 12.3-14 ms
+        int rc = (variant == 0)   ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 8, true, 4, 2>(a, st)
+                 : (variant == 3) ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 4, true, 4, 4>(a, st)
+                 : (variant == 4) ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 8, true, 4, 1>(a, st)
+                                  : pd_zmarch2_launch<T, ND, NONNEG, ANISO, 4, false, 1, 4>(a, st);
         if (rc != TOMO_OK) return rc;
     } else {
         constexpr int RY = 4;
@@ -402,7 +403,7 @@ static size_t tv_skew()
     static long skew = -1;
     if (skew < 0) {
         const char *e = getenv("TOMO_TV_SKEW");
-        skew = e ? atol(e) : 0;
+        skew = e ? atol(e) : 69888;  // 68 KiB + 256 B: measured -13 % on the 1024^3 PD_TV iteration vs 0
         if (skew < 0) skew = 0;
         skew = (skew + 255) / 256 * 256;
     }
