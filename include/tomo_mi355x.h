@@ -143,6 +143,13 @@ int tomo_norm2(const float *x_dev, size_t count, double *out_host, void *stream)
 int tomo_dot(const float *x_dev, const float *y_dev, size_t count, double *out_host, void *stream);
 int tomo_max(const float *x_dev, size_t count, float *out_host, void *stream);
 int tomo_pwls_weights(const float *b_dev, float *w_dev, size_t count, void *stream);
+/* z-slab form of the same: the caller max-all-reduces tomo_pwls_max over the slabs and passes the result on */
+int tomo_pwls_max(const float *b_dev, size_t count, float *out_host, void *stream);
+int tomo_pwls_weights_scaled(const float *b_dev, float *w_dev, size_t count, float wmax, void *stream);
+/* diagnostics: nin-read / nout-write streaming kernel (vec = 4: float4 accesses, 1: dword) used to calibrate the
+ * achievable HBM rate for a kernel's read/write mix (tools/stream_probe.py) */
+int tomo_diag_stream(const float *const *in_dev, int nin, float *const *out_dev, int nout, size_t count,
+                     int vec, int grid, void *stream);
 
 /* ---------------------------------------------------------------- pre/post glue
  * tomo_pad_edge   : edge-pad detX by `pad` both sides, [nz][na][nu0] -> [nz][na][nu0+2pad]

@@ -407,4 +407,95 @@ int orc_roftv(const float *in, float *out, int dx, int dy, int dz, int nd,
     return 0;
 }
 
+/* ---------------------------- single iterations on z-slabs with ghost planes --------------------------------
+ * Test infrastructure for the multi-GPU row: the same arithmetic as orc_pdtv / orc_roftv, one iteration,
+ * on arrays [planes][dy][dx] whose first `out_begin` and last `planes - out_end` planes are read-only ghosts.
+ * first_edge / last_edge say whether plane 0 / plane planes-1 is the GLOBAL first / last slice
+ * (the zIndex > 0 and last_z tests of primal_dual...cu:188,213; the reflecting k indices of rudin_osher...cu:170-171,230). */
+void orc_pdtv_step(const float *in, const float *Ui, float *Uo, const float *P1i, const float *P2i, const float *P3i,
+                   float *P1o, float *P2o, float *P3o, int dx, int dy, int planes, int out_begin, int out_end,
+                   int first_edge, int last_edge, float sigma, float tau, float lt, float theta, int methodTV,
+                   int nonneg, int half)
+{
+    const size_t sy = (size_t)dx, sz = (size_t)dx * dy;
+    const float *Pi[3] = {P1i, P2i, P3i};
+    float *Po[3] = {P1o, P2o, P3o};
+    const int zlo = out_begin > 0 ? out_begin - 1 : 0; /* duals are needed one plane below the first output plane */
+    float *Pn[3];
+    for (int c = 0; c < 3; ++c) Pn[c] = (float *)calloc(sz * (size_t)planes, sizeof(float));
+    (void)first_edge;
+    for (int z = zlo; z < out_end; ++z)
+        for (int y = 0; y < dy; ++y)
+            for (int x = 0; x < dx; ++x) {
+                size_t idx = (size_t)x + sy * y + sz * z;
+                float g[3], p[3];
+                g[0] = pd_fwd(Ui, idx, x, dx, 1);
+                g[1] = pd_fwd(Ui, idx, y, dy, sy);
+                if (z == planes - 1 && last_edge) g[2] = ((z > 0) ? Ui[idx - sz] : 0.0f) - Ui[idx];
+                else g[2] = Ui[idx + sz] - Ui[idx];
+                for (int c = 0; c < 3; ++c) p[c] = Pi[c][idx];
+                pd_dual(p, g, 3, sigma, methodTV);
+                for (int c = 0; c < 3; ++c) Pn[c][idx] = p[c];
+            }
+    for (int z = out_begin; z < out_end; ++z)
+        for (int y = 0; y < dy; ++y)
+            for (int x = 0; x < dx; ++x) {
+                size_t idx = (size_t)x + sy * y + sz * z;
+                float u = Ui[idx];
+                if (nonneg && u < 0.0f) u = 0.0f;
+                float pv1 = -(Pn[0][idx] - (x > 0 ? Pn[0][idx - 1] : 0.0f));
+                float pv2 = -(Pn[1][idx] - (y > 0 ? Pn[1][idx - sy] : 0.0f));
+                float pv3 = -(Pn[2][idx] - (z > 0 ? Pn[2][idx - sz] : 0.0f));
+                float div = (pv1 + pv2) + pv3;
+                float t = fmaf(-tau, div, u);
+                t = fmaf(lt, in[idx], t);
+                float nu_ = t / (1.0f + lt);
+                Uo[idx] = fmaf(theta, nu_ - u, nu_);
+                for (int c = 0; c < 3; ++c) Po[c][idx] = store_dual(Pn[c][idx], half);
+            }
+    for (int c = 0; c < 3; ++c) free(Pn[c]);
+}
+
+void orc_roftv_step(const float *in, const float *Ui, float *Uo, int dx, int dy, int planes, int out_begin,
+                    int out_end, int first_edge, int last_edge, float lambda, float tau, int half)
+{
+    const size_t sy = (size_t)dx, sz = (size_t)dx * dy;
+    float *D[3];
+    for (int c = 0; c < 3; ++c) D[c] = (float *)calloc(sz * (size_t)planes, sizeof(float));
+    const int zlo = out_begin > 0 ? out_begin - 1 : 0;
+    for (int k = zlo; k < out_end; ++k) {
+        const int k_hi = (k == planes - 1 && last_edge) ? k - 1 : k + 1;
+        const int k_lo = (k == 0 && first_edge) ? k + 1 : k - 1;
+        for (int j = 0; j < dy; ++j)
+            for (int i = 0; i < dx; ++i) {
+                size_t idx = (size_t)i + sy * j + sz * k;
+                float u = Ui[idx];
+                float nx1 = Ui[(size_t)i + sy * refl_hi(j, dy) + sz * k] - u;
+                float ny1 = Ui[(size_t)refl_hi(i, dx) + sy * j + sz * k] - u;
+                float nx0 = u - Ui[(size_t)i + sy * refl_lo(j) + sz * k];
+                float ny0 = u - Ui[(size_t)refl_lo(i) + sy * j + sz * k];
+                float nz1 = Ui[(size_t)i + sy * j + sz * k_hi] - u;
+                float nz0 = u - Ui[(size_t)i + sy * j + sz * k_lo];
+                float dxm = rof_minmod_sq(nx0, nx1), dym = rof_minmod_sq(ny0, ny1), dzm = rof_minmod_sq(nz0, nz1);
+                D[0][idx] = store_dual(rof_norm(nx1, nx1 * nx1, dym, dzm), half);
+                D[1][idx] = store_dual(rof_norm(ny1, dxm, ny1 * ny1, dzm), half);
+                D[2][idx] = store_dual(rof_norm(nz1, dxm, dym, nz1 * nz1), half);
+            }
+    }
+    for (int k = out_begin; k < out_end; ++k) {
+        const int k_lo = (k == 0 && first_edge) ? k + 1 : k - 1;
+        for (int j = 0; j < dy; ++j)
+            for (int i = 0; i < dx; ++i) {
+                size_t idx = (size_t)i + sy * j + sz * k;
+                float u = Ui[idx];
+                float dv = (D[0][idx] - D[0][(size_t)i + sy * refl_lo(j) + sz * k]) +
+                           (D[1][idx] - D[1][(size_t)refl_lo(i) + sy * j + sz * k]);
+                dv = dv + (D[2][idx] - D[2][(size_t)i + sy * j + sz * k_lo]);
+                float t = fmaf(lambda, dv, -(u - in[idx]));
+                Uo[idx] = fmaf(tau, t, u);
+            }
+    }
+    for (int c = 0; c < 3; ++c) free(D[c]);
+}
+
 int orc_abi_version(void) { return 1; }

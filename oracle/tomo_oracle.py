@@ -213,6 +213,38 @@ def rof_tv(data, regularisation_parameter=1e-5, iterations=3000, time_marching_p
     return np.expand_dims(out, axis) if is2d else out
 
 
+def pd_step_slab(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, has_lo, has_hi, sigma, tau, lt, theta, methodTV,
+                 nonneg, half):
+    """One PD_TV iteration on a ghosted z-slab (same signature as tomobar_amd.slab._hip_pd_step; CPU torch tensors).
+    Used by the gloo tests of the halo-exchange logic."""
+    import torch
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.orc_pdtv_step.argtypes = [fp] * 9 + [C.c_int] * 7 + [C.c_float] * 4 + [C.c_int] * 3
+    L.orc_pdtv_step.restype = None
+    lo = 1 if has_lo else 0
+    planes = nzl + lo + (1 if has_hi else 0)
+    pin = [np.ascontiguousarray(p.numpy().astype(np.float32)) for p in p_in]
+    pout = [np.zeros_like(a) for a in pin]
+    uo = u_out.numpy()
+    L.orc_pdtv_step(_fptr(inp.numpy()), _fptr(u_in.numpy()), _fptr(uo), _fptr(pin[0]), _fptr(pin[1]), _fptr(pin[2]),
+                    _fptr(pout[0]), _fptr(pout[1]), _fptr(pout[2]), dx, dy, planes, lo, lo + nzl,
+                    0 if has_lo else 1, 0 if has_hi else 1, sigma, tau, lt, theta, int(bool(methodTV)),
+                    int(bool(nonneg)), int(bool(half)))
+    for c in range(3):
+        p_out[c][lo:lo + nzl] = torch.from_numpy(pout[c][lo:lo + nzl]).to(p_out[c].dtype)
+
+
+def rof_step_slab(inp, u_in, u_out, dx, dy, nzl, lo, hi, lam, tau, half):
+    """One ROF_TV iteration on a ghosted z-slab (signature of tomobar_amd.slab._hip_rof_step)."""
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.orc_roftv_step.argtypes = [fp] * 3 + [C.c_int] * 7 + [C.c_float] * 2 + [C.c_int]
+    L.orc_roftv_step.restype = None
+    L.orc_roftv_step(_fptr(inp.numpy()), _fptr(u_in.numpy()), _fptr(u_out.numpy()), dx, dy, nzl + lo + hi, lo,
+                     lo + nzl, 0 if lo else 1, 0 if hi else 1, lam, tau, int(bool(half)))
+
+
 def prox(X, reg, nonneg_regul):
     """regularisersCuPy.py:6-38"""
     if "ROF_TV" in reg["method"]:

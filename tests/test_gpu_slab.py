@@ -1,0 +1,78 @@
+"""GPU test of the z-slab TV kernels (tomo_pdtv_iter_slab / tomo_roftv_iter_slab): one volume is cut into slabs that all
+live on the single test GPU; the slab drivers of tomobar_amd.slab run on each of them with the ghost planes refreshed by
+direct copies (what RCCL send/recv does between GPUs), and the stitched result must equal the whole-volume operator bit
+for bit.  The multi-process exchange itself is covered on CPU by tests/test_slab_gloo.py."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _copy_halos(states, b):
+    """rank r's send_up -> rank r+1's recv_down; rank r+1's send_down -> rank r's recv_up."""
+    for r in range(len(states) - 1):
+        lo, hi = states[r], states[r + 1]
+        for src, dst in zip(lo.send_up(b), hi.recv_down(b)):
+            dst.copy_(src)
+        for src, dst in zip(hi.send_down(b), lo.recv_up(b)):
+            dst.copy_(src)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_pdtv_slabs_equal_whole_volume(world, half, variant):
+    from tomobar_amd import ops
+    from tomobar_amd.regularisersCuPy import PD_TV_cupy
+    from tomobar_amd.slab import PdSlab, _hip_pd_step, slab_bounds
+    ops.set_variant("pdtv", variant)
+    try:
+        nz, dy, dx = 23, 37, 150
+        rng = np.random.default_rng(9)
+        vol = (rng.random((nz, dy, dx)) * 0.3 + (np.indices((nz, dy, dx))[2] > dx // 2) - 0.5).astype(np.float32)
+        vd = torch.from_numpy(vol).cuda()
+        iters = 7
+        want = PD_TV_cupy(vd, 0.04, iters, 0, 1, 8.0, 0, half).cpu().numpy()
+        tau = np.float32(0.04 * 0.1)
+        sigma = np.float32(1.0 / (8.0 * tau))
+        lt = np.float32(tau / 0.04)
+        states = []
+        for r in range(world):
+            z0, z1 = slab_bounds(nz, world, r)
+            states.append(PdSlab(vd[z0:z1].contiguous(), r > 0, r < world - 1, half, _hip_pd_step))
+        for r in range(world - 1):  # ghosts of the initial primal variable
+            states[r + 1].recv_down(0)[0].copy_(states[r].send_up(0)[0])
+            states[r].recv_up(0)[0].copy_(states[r + 1].send_down(0)[0])
+        for it in range(iters):
+            for s in states:
+                s.step(it, sigma, tau, lt, np.float32(1.0), 0, 1)
+            _copy_halos(states, (it + 1) & 1)
+        got = torch.cat([s.local(s.U[iters & 1]) for s in states]).cpu().numpy()
+        assert np.array_equal(got, want), np.abs(got - want).max()
+    finally:
+        ops.set_variant("pdtv", 0)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("half", [False, True])
+def test_roftv_slabs_equal_whole_volume(world, half):
+    from tomobar_amd.regularisersCuPy import ROF_TV_cupy
+    from tomobar_amd.slab import RofSlab, _hip_rof_step, slab_bounds
+    nz, dy, dx = 19, 21, 90
+    rng = np.random.default_rng(10)
+    vol = (rng.random((nz, dy, dx)) * 0.3 + (np.indices((nz, dy, dx))[2] > dx // 2)).astype(np.float32)
+    vd = torch.from_numpy(vol).cuda()
+    iters = 6
+    want = ROF_TV_cupy(vd, 0.05, iters, 0.005, 0, half).cpu().numpy()
+    states = []
+    for r in range(world):
+        z0, z1 = slab_bounds(nz, world, r)
+        states.append(RofSlab(vd[z0:z1].contiguous(), r > 0, r < world - 1, half, _hip_rof_step))
+    _copy_halos(states, 0)
+    for it in range(iters):
+        for s in states:
+            s.step(it, np.float32(0.05), np.float32(0.005))
+        _copy_halos(states, (it + 1) & 1)
+    got = torch.cat([s.local(s.U[iters & 1]) for s in states]).cpu().numpy()
+    assert np.array_equal(got, want), np.abs(got - want).max()

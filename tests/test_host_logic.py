@@ -1,0 +1,163 @@
+"""CPU tests of the host side: C-ABI surface, dictionary handling, axis swapping, geometry bookkeeping.
+(No compute entry point is called here: that needs a GPU and lives in the -m gpu tests.)"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from tomobar_amd import _lib
+    header = open(os.path.join(ROOT, "include", "tomo_mi355x.h")).read()
+    declared = set(re.findall(r"\b(tomo_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    handle = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(handle, name), f"{name} declared in include/tomo_mi355x.h but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert handle.tomo_abi_version() == 1
+    assert C.sizeof(_lib.AngleRecord) == 32
+
+
+def test_no_gpu_means_loud_failure():
+    """The product path has no CPU fallback: without a device every constructor raises."""
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from tomobar_amd import _lib
+    from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    with pytest.raises(_lib.TomoRuntimeError):
+        RecToolsIRCuPy(16, 0, 4, 0.0, np.linspace(0, np.pi, 8), 16)
+    n = C.c_int(-1)
+    assert _lib.lib().tomo_device_count(C.byref(n)) == _lib.E_NODEVICE
+    assert b"no CPU fallback" in _lib.lib().tomo_last_error()
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "tomobar_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            text = open(os.path.join(dirpath, f), errors="ignore").read() if f.endswith((".py", ".hip", ".h", ".inl")) else ""
+            if f.endswith(".py"):
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+                assert "libtomo_oracle" not in text, f
+            else:  # native sources may cite the oracle in comments but must not include or call it
+                assert not re.search(r"#include[^\n]*oracle", text) and not re.search(r"\borc_[a-z0-9_]+\s*\(", text), f
+
+
+def test_swap_data_axes_tuples():
+    # expected tuples are the reference's own (tests/test_tools.py:36-68)
+    from tomobar_amd.supp.funcs import _swap_data_axes_to_accepted
+    req = ["angles", "detY", "detX"]
+    assert _swap_data_axes_to_accepted(["angles", "detX", "detY"], req) == [(1, 2), None]
+    assert _swap_data_axes_to_accepted(["detX", "angles", "detY"], req) == [(0, 1), (1, 2)]
+    assert _swap_data_axes_to_accepted(["detY", "angles", "detX"], req) == [(0, 1), None]
+    assert _swap_data_axes_to_accepted(["angles", "detY", "detX"], req) == [None, None]
+    with pytest.raises(ValueError):
+        _swap_data_axes_to_accepted(["angles", "detZ", "detX"], req)
+    with pytest.raises(ValueError):
+        _swap_data_axes_to_accepted(["angles", "detX"], req)
+
+
+class _FakeTools:
+    device_index = 0
+
+
+class _FakeSelf:
+    def __init__(self, os_number=1):
+        self.OS_number = os_number
+        self.Atools = _FakeTools()
+
+
+@pytest.fixture
+def cpu_ops(monkeypatch):
+    """dicts_check moves the data to the GPU through ops.to_device; keep it on the CPU for these host-logic tests."""
+    from tomobar_amd import ops
+    monkeypatch.setattr(ops, "to_device", lambda x, d=0: torch.as_tensor(x))
+    monkeypatch.setattr(ops, "contiguous", lambda t: t.contiguous())
+    return ops
+
+
+def test_dicts_check_defaults_match_reference(cpu_ops):
+    # tomobar/supp/dicts.py:83-183 of the reference
+    from tomobar_amd.supp.dicts import dicts_check
+    data = np.zeros((4, 6, 5), np.float32)
+    me = _FakeSelf()
+    d, a, r = dicts_check(me, {"projection_data": data}, None, None, "FISTA")
+    assert d["data_fidelity"] == "LS" and d["data_axes_labels_order"] is None and me.data_fidelity == "LS"
+    assert a == {"iterations": 400, "initialise": None, "nonnegativity": False, "recon_mask_radius": 1.0,
+                 "tolerance": 0.0, "verbose": False}
+    assert r == {"method": None, "regul_param": 0.001, "iterations": 150, "tolerance": 0.0, "time_marching_step": 0.005,
+                 "PD_LipschitzConstant": 12.0, "methodTV": 0, "device_regulariser": 0}
+    assert me.nonneg_regul == 0
+    _, a, _ = dicts_check(_FakeSelf(5), {"projection_data": data}, None, None, "FISTA")
+    assert a["iterations"] == 20
+    _, a, _ = dicts_check(_FakeSelf(), {"projection_data": data}, {"nonnegativity": True}, None, "ADMM")
+    assert (a["iterations"], a["ADMM_rho_const"], a["ADMM_relax_par"]) == (400, 1.0, 1.6)
+    _, a, _ = dicts_check(_FakeSelf(3), {"projection_data": data}, None, None, "ADMM")
+    assert a["iterations"] == 10
+    for method, its in (("SIRT", 200), ("CGLS", 30), ("Landweber", 1500)):
+        _, a, r = dicts_check(_FakeSelf(), {"projection_data": data}, None, None, method)
+        assert a["iterations"] == its and a["lipschitz_const"] == 0 and a["tau_step_lanweber"] == 1e-05
+        assert r == {"method": None}
+    _, a, _ = dicts_check(_FakeSelf(4), {"projection_data": data}, None, None, "OSEM")
+    assert a["iterations"] == 15
+    # the caller's dictionaries are populated in place, unknown keys are kept
+    mine = {"projection_data": data, "mask_diameter": 0.9}
+    dicts_check(_FakeSelf(), mine, None, None, "FISTA")
+    assert mine["data_fidelity"] == "LS" and mine["mask_diameter"] == 0.9
+
+
+def test_dicts_check_errors_and_axis_swap(cpu_ops):
+    from tomobar_amd.supp.dicts import dicts_check
+    data = np.arange(4 * 6 * 5, dtype=np.float32).reshape(4, 6, 5)
+    with pytest.raises(NameError):
+        dicts_check(_FakeSelf(), None)
+    with pytest.raises(NameError):
+        dicts_check(_FakeSelf(), {"projection_data": None})
+    with pytest.raises(ValueError):
+        dicts_check(_FakeSelf(), {"projection_data": data, "data_fidelity": "Huber"})
+    with pytest.raises(ValueError):
+        dicts_check(_FakeSelf(), {"projection_data": data}, {"nonnegativity": 3})
+    for method in ("SIRT", "CGLS", "Landweber"):
+        with pytest.raises(NameError):
+            dicts_check(_FakeSelf(2), {"projection_data": data}, None, None, method)
+    # [angles, detY, detX] -> canonical [detY, angles, detX], materialised contiguous
+    d, _, _ = dicts_check(_FakeSelf(), {"projection_data": data, "data_axes_labels_order": ["angles", "detY", "detX"]})
+    assert tuple(d["projection_data"].shape) == (6, 4, 5) and d["projection_data"].is_contiguous()
+    assert np.array_equal(d["projection_data"].numpy(), np.swapaxes(data, 0, 1))
+    # 2D input becomes one detector row
+    d, _, _ = dicts_check(_FakeSelf(), {"projection_data": data[0], "data_axes_labels_order": ["detX", "angles"]})
+    assert tuple(d["projection_data"].shape) == (1, 5, 6)
+
+
+def test_check_if_input_2d_or_3d_cpu():
+    # tests/test_regularisers.py:7-36 of the reference
+    from tomobar_amd.regularisersCuPy import _check_if_input_2d_or_3d
+    for shape, want in (((100, 100), ((100, 100), True, 0)), ((10, 100, 100), ((10, 100, 100), False, 0)),
+                        ((1, 100, 100), ((100, 100), True, 0)), ((16, 1, 100), ((16, 100), True, 1))):
+        d, flag, ax = _check_if_input_2d_or_3d(torch.zeros(shape))
+        assert (tuple(d.shape), flag, ax) == want
+    with pytest.raises(ValueError):
+        _check_if_input_2d_or_3d(torch.zeros((2, 2, 2, 2)))
+
+
+def test_vec_geom_matches_reference_formula():
+    # tomobar/supp/funcs.py:45-81: ray Rz(t)(0,-1,0), det centre Rz(t)(c0,0,c1), u Rz(t)(1,0,0), v (0,0,1)
+    from tomobar_amd.projector import geom_size, vec_geom_init3D
+    th = np.array([0.0, 0.3, 1.7, 3.0])
+    cor = np.array([[1.5, 0.0], [0.0, 0.0], [-2.0, 0.0], [0.25, 0.0]])
+    v = vec_geom_init3D(th, 1.0, 1.0, cor)
+    for i, t in enumerate(th):
+        R = np.array([[np.cos(t), -np.sin(t), 0], [np.sin(t), np.cos(t), 0], [0, 0, 1.0]])
+        np.testing.assert_allclose(v[i, 0:3], R @ [0, -1, 0], atol=1e-15)
+        np.testing.assert_allclose(v[i, 3:6], R @ [cor[i, 0], 0, cor[i, 1]], atol=1e-15)
+        np.testing.assert_allclose(v[i, 6:9], R @ [1, 0, 0], atol=1e-15)
+        np.testing.assert_allclose(v[i, 9:12], [0, 0, 1], atol=1e-15)
+    assert geom_size({"GridRowCount": 5, "GridColCount": 6, "GridSliceCount": 7}) == (7, 5, 6)
+    assert geom_size({"DetectorRowCount": 3, "DetectorColCount": 9, "Vectors": v}) == (3, 4, 9)

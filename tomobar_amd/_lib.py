@@ -56,6 +56,9 @@ SIGNATURES = {
     "tomo_dot": (_i, [_vp, _vp, _sz, C.POINTER(_d), _vp]),
     "tomo_max": (_i, [_vp, _sz, C.POINTER(_f), _vp]),
     "tomo_pwls_weights": (_i, [_vp, _vp, _sz, _vp]),
+    "tomo_pwls_max": (_i, [_vp, _sz, C.POINTER(_f), _vp]),
+    "tomo_pwls_weights_scaled": (_i, [_vp, _vp, _sz, _f, _vp]),
+    "tomo_diag_stream": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), _i, _sz, _i, _i, _vp]),
     "tomo_pad_edge": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "tomo_crop_center": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "tomo_circ_mask": (_i, [_vp, _i, _i, _d, _vp]),

@@ -285,6 +285,20 @@ extern "C" int tomo_pwls_weights(const float *b, float *w, size_t count, void *s
     return ew_launch<1, 1>(b, nullptr, nullptr, w, nullptr, count, stream, PwlsF{(float)m});
 }
 
+// slab form: the maximum is taken over all slabs by the caller (max-all-reduce) between these two calls
+extern "C" int tomo_pwls_max(const float *b, size_t count, float *out_host, void *stream)
+{
+    double m = 0.0;
+    int rc = reduce_host<RED_MAX_CLAMPED>(b, nullptr, count, &m, stream);
+    if (rc == TOMO_OK) *out_host = (float)m;
+    return rc;
+}
+
+extern "C" int tomo_pwls_weights_scaled(const float *b, float *w, size_t count, float wmax, void *stream)
+{
+    return ew_launch<1, 1>(b, nullptr, nullptr, w, nullptr, count, stream, PwlsF{wmax});
+}
+
 extern "C" int tomo_pad_edge(const float *in, float *out, int rows, int nu0, int pad, void *stream)
 {
     TOMO_REQUIRE(rows >= 0 && nu0 > 0 && pad >= 0, "bad padding arguments");

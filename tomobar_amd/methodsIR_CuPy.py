@@ -59,6 +59,7 @@ class RecToolsIRCuPy:
         self.Atools = HipTools3D(DetectorsDimH, DetectorsDimH_pad, DetectorsDimV, AnglesVec, CenterRotOffset,
                                  ObjSize, "gpu", device_projector, OS_number)
         self.power_seed = None  # set to an int for a reproducible power-method start vector
+        self.slab = None        # tomobar_amd.slab.SlabComm when this object reconstructs one z-slab of a larger volume
 
     @property
     def OS_number(self) -> int:
@@ -84,6 +85,11 @@ class RecToolsIRCuPy:
         return self.Atools._backprojOSCuPy(b, os_index=sub_ind) if os else self.Atools._backprojCuPy(b)
 
     # ------------------------------------------------------------------ shared set-up / tear-down
+    def _gdot(self, x, y) -> float:
+        """Inner product over the whole volume / sinogram (sum-all-reduced over the z-slabs when sharded)."""
+        v = ops.dot(x, y)
+        return v if self.slab is None else self.slab.allreduce_sum(v)
+
     def _new_vol(self, fill=None):
         v = torch.empty(self.Atools.vol_shape(), dtype=torch.float32, device=self.Atools._device)
         if fill is not None:
@@ -121,7 +127,7 @@ class RecToolsIRCuPy:
         if x0 is None:
             x0 = self._new_vol(1.0 if method_run == "OSEM" else 0.0)
         use_os = self.OS_number > 1
-        w = ops.pwls_weights(d["projection_data"]) if _data_["data_fidelity"] in ["PWLS"] else None
+        w = ops.pwls_weights(d["projection_data"], self.slab) if _data_["data_fidelity"] in ["PWLS"] else None
         return (d, a, r, x0, w, use_os)
 
     # ------------------------------------------------------------------ power method
@@ -141,7 +147,10 @@ class RecToolsIRCuPy:
         s = 1.0
         for _ in range(15):
             A.backward(y, sub, out=x1)
-            s = float32(ops.norm2(x1))
+            s = ops.norm2(x1)
+            if self.slab is not None:  # the eigenvector spans all slabs: global 2-norm
+                s = float(np.sqrt(self.slab.allreduce_sum(s * s)))
+            s = float32(s)
             ops.scale(float32(1.0) / s, x1, x1)
             A.forward(x1, sub, out=y)
         return float(s)
@@ -276,16 +285,16 @@ class RecToolsIRCuPy:
         x = self._new_vol(0.0)
         r_vec = d["projection_data"].clone()
         dvec = A.backward(r_vec)
-        normr2 = float32(ops.dot(dvec, dvec))
+        normr2 = float32(self._gdot(dvec, dvec))
         Ad = torch.empty_like(r_vec)
         s = self._new_vol()
         for _ in range(a["iterations"]):
             A.forward(dvec, None, out=Ad)
-            alpha = float32(normr2 / float32(ops.dot(Ad, Ad)))
+            alpha = float32(normr2 / float32(self._gdot(Ad, Ad)))
             ops.axpby(alpha, dvec, 1.0, x)
             ops.axpby(-alpha, Ad, 1.0, r_vec)
             A.backward(r_vec, None, out=s)
-            normr2_new = float32(ops.dot(s, s))
+            normr2_new = float32(self._gdot(s, s))
             beta = float32(normr2_new / normr2)
             normr2 = normr2_new
             ops.axpby(1.0, s, beta, dvec)  # d = s + beta d

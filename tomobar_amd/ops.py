@@ -113,10 +113,17 @@ def dot(x, y) -> float:
     return out.value
 
 
-def pwls_weights(b):
+def pwls_weights(b, slab=None):
+    """w = max(b, 1e-6) / max(max(b, 1e-6)); with a SlabComm the maximum is taken over all z-slabs."""
     w = torch.empty_like(b)
     with torch.cuda.device(b.device):
-        L.check(L.lib().tomo_pwls_weights(ptr(b), ptr(w), b.numel(), stream_ptr(b)))
+        if slab is None:
+            L.check(L.lib().tomo_pwls_weights(ptr(b), ptr(w), b.numel(), stream_ptr(b)))
+        else:
+            m = C.c_float(0.0)
+            L.check(L.lib().tomo_pwls_max(ptr(b), b.numel(), C.byref(m), stream_ptr(b)))
+            wmax = np.float32(slab.allreduce_max(float(m.value)))
+            L.check(L.lib().tomo_pwls_weights_scaled(ptr(b), ptr(w), b.numel(), float(wmax), stream_ptr(b)))
     return w
 
 

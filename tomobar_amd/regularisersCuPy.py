@@ -20,6 +20,19 @@ from . import ops
 def prox_regul(self, X: torch.Tensor, _regularisation_: dict, out=None) -> torch.Tensor:
     """Dispatch on the ``method`` substring exactly like regularisersCuPy.py:16-38."""
     method = _regularisation_["method"]
+    slab = getattr(self, "slab", None)
+    if slab is not None and X.dim() == 3 and min(X.shape) > 1:
+        # the volume is one z-slab of a larger one: 3D TV with ghost planes exchanged between z-neighbours
+        from .slab import pd_tv_slab, rof_tv_slab
+        X = ops.contiguous(X)
+        if "ROF_TV" in method:
+            return rof_tv_slab(X, slab, _regularisation_["regul_param"], _regularisation_["iterations"],
+                               _regularisation_["time_marching_step"], _regularisation_.get("half_precision", False),
+                               out=out)
+        if "PD_TV" in method:
+            return pd_tv_slab(X, slab, _regularisation_["regul_param"], _regularisation_["iterations"],
+                              _regularisation_["methodTV"], self.nonneg_regul, _regularisation_["PD_LipschitzConstant"],
+                              _regularisation_.get("half_precision", False), out=out)
     if "ROF_TV" in method:
         return ROF_TV_cupy(X, _regularisation_["regul_param"], _regularisation_["iterations"],
                            _regularisation_["time_marching_step"], self.Atools.device_index,
