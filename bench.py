@@ -182,8 +182,18 @@ def main():
                 kernels[k] = {"launches": cnt, "avg_ms": avg, "total_ms": ms,
                               "alg_GBps": alg_bytes[k] / avg / 1e6, "frac_hbm": alg_bytes[k] / avg / 1e6 / HBM_PEAK_GBS}
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+        # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/pmc_run.sh;
+        # counters cannot be collected from inside this process); valid only for the configuration they were taken on
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = "pdtv_half" if (dom == "pdtv" and args.half) else dom
+            if key in pmc and (n, nz) == (1024, 1024):
+                traffic = pmc[key]["traffic_bytes"]
+        except (OSError, ValueError):
+            pass
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": kernels[dom]["frac_hbm"], "traffic": None,
+                "frac": kernels[dom]["frac_hbm"], "traffic": traffic,
                 "avg_launch_ms": kernels[dom]["avg_ms"], "launches": kernels[dom]["launches"],
                 "alg_bytes_per_launch": alg_bytes[dom]}
         line = {
