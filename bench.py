@@ -174,11 +174,17 @@ def main():
         V = nz * n * n
         sub = -(-na // args.os)
         S_s = nz * sub * n
-        alg_bytes = {"pdtv": (24 if args.half else 36) * V, "roftv": 12 * V, "bp": 4 * (S_s + V), "fp": 4 * (S_s + V)}
+        # algorithmic bytes per unit of work; one PD_TV launch may carry two inner iterations
+        # (pd_zmarch_x2), so its bytes per launch = bytes per iteration x iterations / launches
+        sub_its = args.steps * args.os
+        alg_total = {"pdtv": (24 if args.half else 36) * V * args.inner * sub_its, "roftv": 12 * V * args.inner * sub_its,
+                     "bp": 4 * (S_s + V) * sub_its, "fp": 4 * (S_s + V) * sub_its}
         kernels = {}
+        alg_bytes = {}
         for k, (cnt, ms) in prof.items():
             if cnt:
                 avg = ms / cnt
+                alg_bytes[k] = alg_total[k] / cnt
                 kernels[k] = {"launches": cnt, "avg_ms": avg, "total_ms": ms,
                               "alg_GBps": alg_bytes[k] / avg / 1e6, "frac_hbm": alg_bytes[k] / avg / 1e6 / HBM_PEAK_GBS}
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"])

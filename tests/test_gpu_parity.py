@@ -178,7 +178,7 @@ TV_SHAPES = [(6, 9, 13), (1, 20, 17), (12, 1, 70), (10, 11, 1), (8, 8, 8), (3, 5
 
 
 @pytest.mark.parametrize("shape", TV_SHAPES)
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_pdtv_vs_oracle(oracle, ops, shape, variant):
     from tomobar_amd.regularisersCuPy import PD_TV_cupy
     ops.set_variant("pdtv", variant)

@@ -240,6 +240,29 @@ __global__ __launch_bounds__(256) void pd_zmarch_kernel(PdArgs a)
 }
 
 #include "pd_zmarch2.inl"
+#include "pd_zmarch_x2.inl"
+
+// two iterations in one pass (3D, whole volume only).  variant 0: 4 rows; 6: 6 rows; 7: 4x1 waves 4 rows
+template <typename T>
+int pd_pair_launch(const PdArgs &a, int methodTV, int nonneg, int variant, hipStream_t st)
+{
+#define PD_X2(NN, AN)                                                                                          \
+    /* measured, 1024^3 f32 duals, ms per iteration: 2x2 waves 5.60 | 2x1 5.74 | 4x1 6.20 | 4x2 7.10 | 8x1 8.28 */ \
+    (variant == 6 ? pd_zmarch_x2_launch<T, NN, AN, 4, 4, 2>(a, st)                                              \
+                  : variant == 7 ? pd_zmarch_x2_launch<T, NN, AN, 4, 2, 1>(a, st)                               \
+                  : variant == 8 ? pd_zmarch_x2_launch<T, NN, AN, 4, 8, 1>(a, st)                               \
+                  : variant == 9 ? pd_zmarch_x2_launch<T, NN, AN, 4, 4, 1>(a, st)                               \
+                                 : pd_zmarch_x2_launch<T, NN, AN, 4, 2, 2>(a, st))
+    int rc;
+    if (!nonneg && !methodTV) rc = PD_X2(false, false);
+    else if (nonneg && !methodTV) rc = PD_X2(true, false);
+    else if (!nonneg && methodTV) rc = PD_X2(false, true);
+    else rc = PD_X2(true, true);
+#undef PD_X2
+    if (rc != TOMO_OK) return rc;
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
 
 template <typename T, int ND, bool NONNEG, bool ANISO>
 int pd_launch(const PdArgs &a0, int variant, hipStream_t st)
@@ -292,7 +315,7 @@ int pd_dispatch(const PdArgs &a, int methodTV, int nonneg, int variant, hipStrea
 
 int pd_iter(const PdArgs &a, int nd, int methodTV, int nonneg, int half, hipStream_t st)
 {
-    const int v = g_variant_pdtv;
+    const int v = (g_variant_pdtv >= 6 && g_variant_pdtv <= 9) ? 0 : g_variant_pdtv;  // 6-9 only differ in the paired kernel
     if (nd == 3) return half ? pd_dispatch<__half, 3>(a, methodTV, nonneg, v, st) : pd_dispatch<float, 3>(a, methodTV, nonneg, v, st);
     return half ? pd_dispatch<__half, 2>(a, methodTV, nonneg, v, st) : pd_dispatch<float, 2>(a, methodTV, nonneg, v, st);
 }
@@ -457,23 +480,36 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
     // U_arrays[0] = data.copy() is not materialised: iteration 0 reads the caller's buffer directly;
     // duals start at zero (regularisersCuPy.py:221-223); every U / P output buffer is fully overwritten
     for (int c = 0; c < nd; ++c) TOMO_HIP(hipMemsetAsync(P[0][c], 0, pb, st));
-    tomo_prof_scope prof(PROF_PDTV, st, iters);
-    for (int it = 0; it < iters; ++it) {
-        const int ib = it & 1, ob = ib ^ 1;
+    // 3D volumes run two iterations per launch (pd_zmarch_x2) while at least two remain; variants 1-5 keep one
+    // iteration per launch (A/B measurement)
+    const int v = g_variant_pdtv;
+    const bool pairs = (nd == 3) && (v == 0 || (v >= 6 && v <= 9)) && !getenv("TOMO_PD_NOPAIR");
+    int launches = 0;
+    for (int it = 0; it < iters;) launches += 1, it += (pairs && iters - it >= 2) ? 2 : 1;
+    tomo_prof_scope prof(PROF_PDTV, st, launches);
+    int cset = 0;  // buffer set holding the current iterate (iteration 0 reads the caller's buffer instead of U[0])
+    for (int it = 0; it < iters;) {
+        const bool pair = pairs && (iters - it >= 2);
+        const int step = pair ? 2 : 1;
+        const int ib = cset, ob = cset ^ 1;
         PdArgs a;
         a.in = in_dev;
         a.u_in = (it == 0) ? in_dev : U[ib];
-        // the last iteration writes straight into the caller's output buffer (unless it aliases the input)
-        a.u_out = (it == iters - 1 && out_dev != in_dev) ? out_dev : U[ob];
+        // the last launch writes straight into the caller's output buffer (unless it aliases the input)
+        const bool last = (it + step == iters);
+        a.u_out = (last && out_dev != in_dev) ? out_dev : U[ob];
         for (int c = 0; c < 3; ++c) { a.p_in[c] = P[ib][c]; a.p_out[c] = P[ob][c]; }
         a.dx = dx; a.dy = dy; a.planes = dz; a.out_begin = 0; a.out_end = dz;
         a.first_is_edge = 1; a.last_is_edge = 1;
         a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = dz;
-        rc = pd_iter(a, nd, methodTV, nonneg, half, st);
+        if (pair) rc = half ? pd_pair_launch<__half>(a, methodTV, nonneg, v, st) : pd_pair_launch<float>(a, methodTV, nonneg, v, st);
+        else rc = pd_iter(a, nd, methodTV, nonneg, half, st);
         if (rc != TOMO_OK) return rc;
+        cset = ob;
+        it += step;
     }
     if (out_dev == in_dev)
-        TOMO_HIP(hipMemcpyAsync(out_dev, U[iters & 1], nvox * sizeof(float), hipMemcpyDeviceToDevice, st));
+        TOMO_HIP(hipMemcpyAsync(out_dev, U[cset], nvox * sizeof(float), hipMemcpyDeviceToDevice, st));
     return TOMO_OK;
 }
 
