@@ -193,6 +193,14 @@ int tomo_pdtv_iter_slab(int device, const float *in_dev, const float *u_in_dev, 
                         const void *p_in_dev[3], void *p_out_dev[3], int dx, int dy, int nz_local,
                         int has_lo, int has_hi, float sigma, float tau, float lt, float theta,
                         int methodTV, int nonneg, int half, void *stream);
+/* Two PD-TV iterations in one pass on a slab: arrays address [lo_planes + nz_local + hi_planes][dy][dx] with
+ * lo_planes, hi_planes in {0, 2}.  Ghost planes that must be valid on entry: U two planes either side; P two planes
+ * below and the first plane above; Input the nearer plane either side.  Result = two applications of
+ * tomo_pdtv_iter_slab with a ghost refresh in between, bit for bit. */
+int tomo_pdtv_pair_slab(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
+                        const void *p_in_dev[3], void *p_out_dev[3], int dx, int dy, int nz_local,
+                        int lo_planes, int hi_planes, float sigma, float tau, float lt, float theta,
+                        int methodTV, int nonneg, int half, void *stream);
 int tomo_roftv_iter_slab(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
                          int dx, int dy, int nz_local, int lo_planes, int hi_planes,
                          float lambda, float tau, int half, void *stream);

@@ -235,6 +235,37 @@ def pd_step_slab(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, has_lo, has_hi, sig
         p_out[c][lo:lo + nzl] = torch.from_numpy(pout[c][lo:lo + nzl]).to(p_out[c].dtype)
 
 
+def pd_pair_slab(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, lo, hi, sigma, tau, lt, theta, methodTV, nonneg, half):
+    """Two PD_TV iterations on a slab with two-plane ghosts (signature of tomobar_amd.slab._hip_pd_pair), as two
+    applications of orc_pdtv_step: the first one also produces the planes next to the slab that the second one reads."""
+    import torch
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.orc_pdtv_step.argtypes = [fp] * 9 + [C.c_int] * 7 + [C.c_float] * 4 + [C.c_int] * 3
+    L.orc_pdtv_step.restype = None
+    planes = nzl + lo + hi
+    first_edge, last_edge = (0 if lo else 1), (0 if hi else 1)
+    i_np, u0 = inp.numpy(), u_in.numpy()
+    # stale garbage in never-consumed ghost planes must not be NaN for the CPU run: work on sanitised copies
+    i_np = np.nan_to_num(i_np.copy())
+    pin = [np.nan_to_num(np.ascontiguousarray(p.numpy().astype(np.float32))) for p in p_in]
+    u0 = np.nan_to_num(u0.copy())
+    u1 = np.zeros_like(u0)
+    p1 = [np.zeros_like(a) for a in pin]
+    b1, e1 = (1 if lo else 0), (planes - 1 if hi else planes)
+    L.orc_pdtv_step(_fptr(i_np), _fptr(u0), _fptr(u1), _fptr(pin[0]), _fptr(pin[1]), _fptr(pin[2]), _fptr(p1[0]),
+                    _fptr(p1[1]), _fptr(p1[2]), dx, dy, planes, b1, e1, first_edge, last_edge, sigma, tau, lt, theta,
+                    int(bool(methodTV)), int(bool(nonneg)), int(bool(half)))
+    u2 = np.zeros_like(u0)
+    p2 = [np.zeros_like(a) for a in pin]
+    L.orc_pdtv_step(_fptr(i_np), _fptr(u1), _fptr(u2), _fptr(p1[0]), _fptr(p1[1]), _fptr(p1[2]), _fptr(p2[0]),
+                    _fptr(p2[1]), _fptr(p2[2]), dx, dy, planes, lo, lo + nzl, first_edge, last_edge, sigma, tau, lt, theta,
+                    int(bool(methodTV)), int(bool(nonneg)), int(bool(half)))
+    u_out[lo:lo + nzl] = torch.from_numpy(u2[lo:lo + nzl])
+    for c in range(3):
+        p_out[c][lo:lo + nzl] = torch.from_numpy(p2[c][lo:lo + nzl]).to(p_out[c].dtype)
+
+
 def rof_step_slab(inp, u_in, u_out, dx, dy, nzl, lo, hi, lam, tau, half):
     """One ROF_TV iteration on a ghosted z-slab (signature of tomobar_amd.slab._hip_rof_step)."""
     L = lib()

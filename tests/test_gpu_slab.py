@@ -25,31 +25,39 @@ def _copy_halos(states, b):
 def test_pdtv_slabs_equal_whole_volume(world, half, variant):
     from tomobar_amd import ops
     from tomobar_amd.regularisersCuPy import PD_TV_cupy
-    from tomobar_amd.slab import PdSlab, _hip_pd_step, slab_bounds
+    from tomobar_amd.slab import PdSlab, _hip_pd_pair, _hip_pd_step, slab_bounds
     ops.set_variant("pdtv", variant)
     try:
         nz, dy, dx = 23, 37, 150
         rng = np.random.default_rng(9)
         vol = (rng.random((nz, dy, dx)) * 0.3 + (np.indices((nz, dy, dx))[2] > dx // 2) - 0.5).astype(np.float32)
         vd = torch.from_numpy(vol).cuda()
-        iters = 7
-        want = PD_TV_cupy(vd, 0.04, iters, 0, 1, 8.0, 0, half).cpu().numpy()
         tau = np.float32(0.04 * 0.1)
         sigma = np.float32(1.0 / (8.0 * tau))
         lt = np.float32(tau / 0.04)
-        states = []
-        for r in range(world):
-            z0, z1 = slab_bounds(nz, world, r)
-            states.append(PdSlab(vd[z0:z1].contiguous(), r > 0, r < world - 1, half, _hip_pd_step))
-        for r in range(world - 1):  # ghosts of the initial primal variable
-            states[r + 1].recv_down(0)[0].copy_(states[r].send_up(0)[0])
-            states[r].recv_up(0)[0].copy_(states[r + 1].send_down(0)[0])
-        for it in range(iters):
-            for s in states:
-                s.step(it, sigma, tau, lt, np.float32(1.0), 0, 1)
-            _copy_halos(states, (it + 1) & 1)
-        got = torch.cat([s.local(s.U[iters & 1]) for s in states]).cpu().numpy()
-        assert np.array_equal(got, want), np.abs(got - want).max()
+        for iters in (7, 4):  # pairs + an odd trailing iteration / pairs only
+            want = PD_TV_cupy(vd, 0.04, iters, 0, 1, 8.0, 0, half).cpu().numpy()
+            states = []
+            for r in range(world):
+                z0, z1 = slab_bounds(nz, world, r)
+                states.append(PdSlab(vd[z0:z1].contiguous(), r > 0, r < world - 1, half, _hip_pd_pair, _hip_pd_step))
+            for r in range(world - 1):  # static Input ghosts and the ghosts of the initial primal variable
+                lo, hi = states[r], states[r + 1]
+                for src, dst in zip(lo.input_send_up() + lo.send_up(0)[:2], hi.input_recv_down() + hi.recv_down(0)[:2]):
+                    dst.copy_(src)
+                for src, dst in zip(hi.input_send_down() + hi.send_down(0)[:2], lo.input_recv_up() + lo.recv_up(0)[:2]):
+                    dst.copy_(src)
+            it = 0
+            while it < iters:
+                for s in states:
+                    if iters - it >= 2:
+                        s.pair(sigma, tau, lt, np.float32(1.0), 0, 1)
+                    else:
+                        s.single(sigma, tau, lt, np.float32(1.0), 0, 1)
+                it += 2 if iters - it >= 2 else 1
+                _copy_halos(states, states[0].cur)
+            got = torch.cat([s.result() for s in states]).cpu().numpy()
+            assert np.array_equal(got, want), (iters, np.abs(got - want).max())
     finally:
         ops.set_variant("pdtv", 0)
 

@@ -40,7 +40,7 @@ def _worker(rank, world, port, case):
         if case["kind"] == "pd":
             want = O.pd_tv(vol, 0.04, case["iters"], case["mtv"], case["nn"], 8.0, case["half"])
             got = pd_tv_slab(mine, comm, 0.04, case["iters"], case["mtv"], case["nn"], 8.0, case["half"],
-                             step_fn=O.pd_step_slab)
+                             pair_fn=O.pd_pair_slab, step_fn=O.pd_step_slab)
         else:
             want = O.rof_tv(vol, 0.05, case["iters"], 0.005, case["half"])
             got = rof_tv_slab(mine, comm, 0.05, case["iters"], 0.005, case["half"], step_fn=O.rof_step_slab)

@@ -70,6 +70,8 @@ SIGNATURES = {
     "tomo_release_scratch": (_i, [_i]),
     "tomo_pdtv_iter_slab": (_i, [_i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i,
                                  _f, _f, _f, _f, _i, _i, _i, _vp]),
+    "tomo_pdtv_pair_slab": (_i, [_i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i,
+                                 _f, _f, _f, _f, _i, _i, _i, _vp]),
     "tomo_roftv_iter_slab": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "tomo_set_variant": (_i, [C.c_char_p, _i]),
     "tomo_profile_enable": (_i, [_i]),

@@ -530,7 +530,32 @@ extern "C" int tomo_pdtv_iter_slab(int device, const float *in_dev, const float 
     a.first_is_edge = has_lo ? 0 : 1;
     a.last_is_edge = has_hi ? 0 : 1;
     a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = nz_local;
+    tomo_prof_scope prof(PROF_PDTV, as_stream(stream), 1);
     return pd_iter(a, 3, methodTV, nonneg, half, as_stream(stream));
+}
+
+extern "C" int tomo_pdtv_pair_slab(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
+                                   const void *p_in_dev[3], void *p_out_dev[3], int dx, int dy, int nz_local,
+                                   int lo_planes, int hi_planes, float sigma, float tau, float lt, float theta,
+                                   int methodTV, int nonneg, int half, void *stream)
+{
+    TOMO_REQUIRE(device >= 0 && dx > 0 && dy > 0 && nz_local >= 2, "bad slab arguments (a slab needs >= 2 slices)");
+    TOMO_REQUIRE((lo_planes == 0 || lo_planes == 2) && (hi_planes == 0 || hi_planes == 2),
+                 "the two-iteration slab kernel needs 0 or 2 ghost planes on either side");
+    TOMO_HIP(hipSetDevice(device));
+    PdArgs a;
+    a.in = in_dev; a.u_in = u_in_dev; a.u_out = u_out_dev;
+    for (int c = 0; c < 3; ++c) { a.p_in[c] = p_in_dev[c]; a.p_out[c] = p_out_dev[c]; }
+    a.dx = dx; a.dy = dy;
+    a.planes = nz_local + lo_planes + hi_planes;
+    a.out_begin = lo_planes;
+    a.out_end = lo_planes + nz_local;
+    a.first_is_edge = lo_planes ? 0 : 1;
+    a.last_is_edge = hi_planes ? 0 : 1;
+    a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = nz_local;
+    hipStream_t st = as_stream(stream);
+    tomo_prof_scope prof(PROF_PDTV, st, 1);
+    return half ? pd_pair_launch<__half>(a, methodTV, nonneg, 0, st) : pd_pair_launch<float>(a, methodTV, nonneg, 0, st);
 }
 
 extern "C" int tomo_roftv(int device, const float *in_dev, float *out_dev, int dx, int dy, int dz, int nd,

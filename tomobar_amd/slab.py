@@ -5,16 +5,17 @@ The parallel-beam projector pair is block-diagonal over z (detector row k <-> sl
 slab of slices of the volume(s) and the matching detector rows of the sinogram; forward / back projection and all
 element-wise glue need no communication.  What does:
 
-  * 3D TV couples neighbouring slices.  One PD_TV iteration at the first slice of a slab reads, from the slab below,
-    the last plane of U and of P1..P3 (to redo that plane's dual update) and, at the last slice, the first plane of U
-    of the slab above.  ROF_TV reads two planes of U from below and one from above.  The slab arrays therefore carry
-    ghost planes which are refreshed after every inner iteration by point-to-point send/recv between z-neighbours
-    (RCCL over xGMI: one direct link per neighbour, no ring).
+  * 3D TV couples neighbouring slices.  The slab arrays carry ghost planes which are refreshed by point-to-point
+    send/recv between z-neighbours (RCCL over xGMI: one direct link per neighbour, no ring):
+      - PD_TV runs TWO iterations per kernel pass (tomo_pdtv_pair_slab), so the ghosts are two planes deep and are
+        refreshed once per pair: 8 planes up (U and P1..3 of the last two slices), 5 planes down (U of the first two
+        slices, P1..3 of the first); an odd trailing iteration uses tomo_pdtv_iter_slab on the same arrays;
+      - ROF_TV: two planes of U up, one down, every iteration.
   * scalar reductions (power-method norm, PWLS weight maximum, CGLS inner products): all-reduce.
 
 ``SlabComm`` wraps ``torch.distributed`` (backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests).  The TV drivers are
-written against a tiny "step" interface so that the same halo logic runs on the HIP kernels
-(``tomo_pdtv_iter_slab`` / ``tomo_roftv_iter_slab``) and, in the CPU tests, on the oracle's single-iteration functions.
+written against small "step" callables so that the same halo logic runs on the HIP kernels and, in the CPU tests, on
+the oracle's single-iteration functions.
 """
 
 from __future__ import annotations
@@ -56,10 +57,11 @@ class SlabComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
-    # ---- halo exchange: lists of (tensor_to_send, tensor_to_fill) towards / from each neighbour
+    # ---- halo exchange
     def exchange(self, send_down: List[torch.Tensor], recv_down: List[torch.Tensor],
                  send_up: List[torch.Tensor], recv_up: List[torch.Tensor]):
-        """send_down/recv_down talk to rank-1, send_up/recv_up to rank+1.  All planes are contiguous views."""
+        """send_down/recv_down talk to rank-1, send_up/recv_up to rank+1.  All planes are contiguous views; the k-th
+        tensor sent up by rank r lands in the k-th tensor of rank r+1's recv_down (and likewise downwards)."""
         ops = []
         P2POp = self.dist.P2POp
         if self.has_lo:
@@ -73,94 +75,152 @@ class SlabComm:
                 req.wait()
 
 
-class LocalPeers:
-    """In-process stand-in for SlabComm used by single-GPU tests: several slabs of one volume live in one process and
-    their ghost planes are refreshed by direct copies.  `peers[r]` is the driver object of slab r."""
-
-    def __init__(self, rank: int, world: int):
-        self.rank, self.world = rank, world
-        self.has_lo = rank > 0
-        self.has_hi = rank < world - 1
-
-
 # ------------------------------------------------------------------------------------------------ PD_TV on a slab
 class PdSlab:
-    """State of a slab-sharded PD_TV run: ghosted ping-pong arrays and the halo bookkeeping.
+    """Ghosted ping-pong state of a slab-sharded PD_TV run.
 
-    Arrays address ``[has_lo + nz_local + has_hi][dy][dx]``; plane index ``lo = has_lo`` is the first local plane.
-    ``step(it)`` performs one Chambolle-Pock iteration on the local planes (reading the ghosts); ``halo_out(it)``
-    returns what the neighbours need from this slab; ``halo_in(it)`` the ghost views to fill."""
+    Arrays address ``[lo + nz_local + hi][dy][dx]`` with ``lo = 2`` below an interior boundary (else 0) and ``hi = 2``
+    above one (else 0); the first local plane is index ``lo``."""
 
-    def __init__(self, data: torch.Tensor, has_lo: bool, has_hi: bool, half: bool, step_fn: Callable):
+    def __init__(self, data: torch.Tensor, has_lo: bool, has_hi: bool, half: bool, pair_fn: Callable, step_fn: Callable):
         nzl, dy, dx = data.shape
+        if (has_lo or has_hi) and nzl < 2:
+            raise ValueError("PD_TV slabs must hold at least two slices")
         self.nzl, self.dy, self.dx = nzl, dy, dx
         self.has_lo, self.has_hi = bool(has_lo), bool(has_hi)
-        self.lo = 1 if has_lo else 0
-        planes = nzl + self.lo + (1 if has_hi else 0)
+        self.lo = 2 if has_lo else 0
+        self.hi = 2 if has_hi else 0
+        planes = nzl + self.lo + self.hi
         dev = data.device
         pd = torch.float16 if half else torch.float32
         self.half = bool(half)
-        # only the initial duals need zeros; every other plane is either copied, received or overwritten before use
+        # only the initial duals need zeros; every other plane that influences an output is copied, received or
+        # overwritten before it is read (the outermost Input ghost only feeds warm-up values that are discarded)
         self.inp = torch.empty((planes, dy, dx), dtype=torch.float32, device=dev)
         self.inp[self.lo:self.lo + nzl] = data
         self.U = [torch.empty((planes, dy, dx), dtype=torch.float32, device=dev) for _ in range(2)]
         self.U[0][self.lo:self.lo + nzl] = data
         self.P = [[torch.zeros((planes, dy, dx), dtype=pd, device=dev) for _ in range(3)],
                   [torch.empty((planes, dy, dx), dtype=pd, device=dev) for _ in range(3)]]
-        self.step_fn = step_fn
+        self.pair_fn, self.step_fn = pair_fn, step_fn
+        self.cur = 0  # buffer set holding the current iterate
 
     def local(self, t: torch.Tensor) -> torch.Tensor:
         return t[self.lo:self.lo + self.nzl]
 
-    def step(self, it: int, sigma, tau, lt, theta, methodTV, nonneg):
-        i, o = it & 1, (it + 1) & 1
-        self.step_fn(self.inp, self.U[i], self.U[o], self.P[i], self.P[o], self.dx, self.dy, self.nzl,
-                     self.has_lo, self.has_hi, sigma, tau, lt, theta, methodTV, nonneg, self.half)
+    def result(self) -> torch.Tensor:
+        return self.local(self.U[self.cur])
 
-    # planes of buffer set `b` that go down (to rank-1: it needs our first U plane as its hi ghost) and up (to rank+1:
-    # it needs our last U, P1, P2, P3 planes as its lo ghosts)
-    def send_down(self, b: int):
-        return [self.U[b][self.lo]]
+    def pair(self, sigma, tau, lt, theta, methodTV, nonneg):
+        i, o = self.cur, self.cur ^ 1
+        self.pair_fn(self.inp, self.U[i], self.U[o], self.P[i], self.P[o], self.dx, self.dy, self.nzl, self.lo, self.hi,
+                     sigma, tau, lt, theta, methodTV, nonneg, self.half)
+        self.cur = o
 
+    def single(self, sigma, tau, lt, theta, methodTV, nonneg):
+        """One iteration on the same arrays: the single-iteration kernel sees one ghost plane either side, i.e. the
+        arrays shifted by one plane where a two-plane ghost exists."""
+        i, o = self.cur, self.cur ^ 1
+        s = 1 if self.has_lo else 0
+        n = self.nzl + (1 if self.has_lo else 0) + (1 if self.has_hi else 0)
+        v = lambda t: t[s:s + n]  # noqa: E731
+        self.step_fn(v(self.inp), v(self.U[i]), v(self.U[o]), [v(p) for p in self.P[i]], [v(p) for p in self.P[o]],
+                     self.dx, self.dy, self.nzl, self.has_lo, self.has_hi, sigma, tau, lt, theta, methodTV, nonneg,
+                     self.half)
+        self.cur = o
+
+    # ---- ghost planes of buffer set b.  Up = to rank+1 (its lo ghosts), down = to rank-1 (its hi ghosts).
     def send_up(self, b: int):
-        last = self.lo + self.nzl - 1
-        return [self.U[b][last]] + [self.P[b][c][last] for c in range(3)]
+        if not self.has_hi:
+            return []
+        l1 = self.lo + self.nzl - 1
+        out = [self.U[b][l1 - 1], self.U[b][l1]]
+        for c in range(3):
+            out += [self.P[b][c][l1 - 1], self.P[b][c][l1]]
+        return out
 
-    def recv_down(self, b: int):  # from rank-1: its last planes -> our lo ghosts
-        return [self.U[b][0]] + [self.P[b][c][0] for c in range(3)] if self.has_lo else []
+    def recv_down(self, b: int):
+        if not self.has_lo:
+            return []
+        out = [self.U[b][0], self.U[b][1]]
+        for c in range(3):
+            out += [self.P[b][c][0], self.P[b][c][1]]
+        return out
 
-    def recv_up(self, b: int):    # from rank+1: its first U plane -> our hi ghost
-        return [self.U[b][self.lo + self.nzl]] if self.has_hi else []
+    def send_down(self, b: int):
+        if not self.has_lo:
+            return []
+        f = self.lo
+        return [self.U[b][f], self.U[b][f + 1]] + [self.P[b][c][f] for c in range(3)]
+
+    def recv_up(self, b: int):
+        if not self.has_hi:
+            return []
+        h = self.lo + self.nzl
+        return [self.U[b][h], self.U[b][h + 1]] + [self.P[b][c][h] for c in range(3)]
+
+    # static Input ghosts: the nearer plane either side
+    def input_send_up(self):
+        return [self.inp[self.lo + self.nzl - 1]] if self.has_hi else []
+
+    def input_recv_down(self):
+        return [self.inp[1]] if self.has_lo else []
+
+    def input_send_down(self):
+        return [self.inp[self.lo]] if self.has_lo else []
+
+    def input_recv_up(self):
+        return [self.inp[self.lo + self.nzl]] if self.has_hi else []
+
+
+def _ptr3(ts):
+    return (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
 
 
 def _hip_pd_step(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, has_lo, has_hi, sigma, tau, lt, theta, methodTV, nonneg, half):
     from . import _lib as L
     from . import ops
-    pin = (C.c_void_p * 3)(*[p.data_ptr() for p in p_in])
-    pout = (C.c_void_p * 3)(*[p.data_ptr() for p in p_out])
     with torch.cuda.device(inp.device):
-        L.check(L.lib().tomo_pdtv_iter_slab(inp.device.index, ops.ptr(inp), ops.ptr(u_in), ops.ptr(u_out), pin, pout,
-                                            dx, dy, nzl, int(has_lo), int(has_hi), float(sigma), float(tau), float(lt),
-                                            float(theta), int(bool(methodTV)), int(bool(nonneg)), int(bool(half)),
-                                            ops.stream_ptr(inp)))
+        L.check(L.lib().tomo_pdtv_iter_slab(inp.device.index, ops.ptr(inp), ops.ptr(u_in), ops.ptr(u_out), _ptr3(p_in),
+                                            _ptr3(p_out), dx, dy, nzl, int(has_lo), int(has_hi), float(sigma),
+                                            float(tau), float(lt), float(theta), int(bool(methodTV)), int(bool(nonneg)),
+                                            int(bool(half)), ops.stream_ptr(inp)))
+
+
+def _hip_pd_pair(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, lo, hi, sigma, tau, lt, theta, methodTV, nonneg, half):
+    from . import _lib as L
+    from . import ops
+    with torch.cuda.device(inp.device):
+        L.check(L.lib().tomo_pdtv_pair_slab(inp.device.index, ops.ptr(inp), ops.ptr(u_in), ops.ptr(u_out), _ptr3(p_in),
+                                            _ptr3(p_out), dx, dy, nzl, int(lo), int(hi), float(sigma), float(tau),
+                                            float(lt), float(theta), int(bool(methodTV)), int(bool(nonneg)),
+                                            int(bool(half)), ops.stream_ptr(inp)))
 
 
 def pd_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, methodTV=0, nonneg=0,
-               lipschitz_const=8.0, half_precision=False, step_fn: Optional[Callable] = None, out=None):
+               lipschitz_const=8.0, half_precision=False, pair_fn: Optional[Callable] = None,
+               step_fn: Optional[Callable] = None, out=None):
     """PD_TV of a z-slab of a larger 3D volume; bit-identical to running PD_TV_cupy on the whole volume."""
     tau = np.float32(regularisation_parameter * 0.1)
     sigma = np.float32(1.0 / (lipschitz_const * tau))
     theta = np.float32(1.0)
     lt = np.float32(tau / regularisation_parameter)
-    st = PdSlab(data, comm.has_lo, comm.has_hi, half_precision, step_fn or _hip_pd_step)
-    # ghosts of the initial primal variable (= the data); the initial duals are zero everywhere
-    comm.exchange(st.send_down(0)[:1], st.recv_down(0)[:1], st.send_up(0)[:1], st.recv_up(0)[:1])
-    for it in range(iterations):
-        st.step(it, sigma, tau, lt, theta, methodTV, nonneg)
-        if it + 1 < iterations:
-            b = (it + 1) & 1
+    st = PdSlab(data, comm.has_lo, comm.has_hi, half_precision, pair_fn or _hip_pd_pair, step_fn or _hip_pd_step)
+    # Input ghosts (static) and the ghosts of the initial primal variable; the initial duals are zero everywhere
+    comm.exchange(st.input_send_down() + st.send_down(0)[:2], st.input_recv_down() + st.recv_down(0)[:2],
+                  st.input_send_up() + st.send_up(0)[:2], st.input_recv_up() + st.recv_up(0)[:2])
+    it = 0
+    while it < iterations:
+        if iterations - it >= 2:
+            st.pair(sigma, tau, lt, theta, methodTV, nonneg)
+            it += 2
+        else:
+            st.single(sigma, tau, lt, theta, methodTV, nonneg)
+            it += 1
+        if it < iterations:
+            b = st.cur
             comm.exchange(st.send_down(b), st.recv_down(b), st.send_up(b), st.recv_up(b))
-    res = st.local(st.U[iterations & 1])
+    res = st.result()
     if out is not None:
         out.copy_(res)
         return out
@@ -198,7 +258,6 @@ class RofSlab:
 
     def send_up(self, b):
         last = self.lo + self.nzl - 1
-        # a one-slice slab forwards nothing useful as "second-to-last"; slabs are required to hold >= 2 slices
         return [self.U[b][last - 1], self.U[b][last]]
 
     def recv_down(self, b):
