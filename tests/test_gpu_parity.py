@@ -196,8 +196,10 @@ def test_pdtv_vs_oracle(oracle, ops, shape, variant):
 
 
 @pytest.mark.parametrize("shape", TV_SHAPES)
-def test_roftv_vs_oracle(oracle, ops, shape):
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_roftv_vs_oracle(oracle, ops, shape, variant):
     from tomobar_amd.regularisersCuPy import ROF_TV_cupy
+    ops.set_variant("roftv", variant)
     rng = np.random.default_rng(6)
     x = (rng.random(shape) * 0.3 + (np.indices(shape)[-1] > shape[-1] // 2)).astype(np.float32)
     for half in (False, True):

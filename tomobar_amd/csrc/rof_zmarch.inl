@@ -1,0 +1,174 @@
+// ROF_TV iteration as a register-blocked z-march (same skeleton as pd_zmarch2).  Included inside the anonymous
+// namespace of tv_kernels.hip (uses RofArgs, rof_mm, rof_norm, DualIO).
+//
+// The reference runs two kernels per iteration (divergence_kernel_* writes D1..D3, TV_kernel_* reads them back:
+// 40 B/voxel, rudin_osher_fatemi_total_variation.cu:106-148,203-248).  The per-voxel fused kernel needs no D arrays but
+// evaluates D four times per voxel from cache.  Here a lane owns RY rows of one x column and marches z: D is evaluated
+// ONCE per voxel (+ one halo row / two halo lanes), D1/D2 neighbours are registers / wave shuffles, D3 of the plane
+// below is carried, so the iteration moves 12 B/voxel (read U, Input; write U).  The only look-ahead is the global
+// z = 0 plane, whose backward difference reflects to D3 of plane 1 (:228-235): it is evaluated in the first step.
+struct RofD { float d1, d2, d3; };
+
+template <int ND, bool HALF>
+__device__ __forceinline__ RofD rof_eval(float u, float u_i1, float u_i2, float u_j1, float u_j2, float u_k1, float u_k2)
+{
+    // reference naming: "x" differences run along j (rows), "y" along i (lanes)  (rudin_osher...cu:183-188)
+    const float nx1 = u_j1 - u, nx0 = u - u_j2;
+    const float ny1 = u_i1 - u, ny0 = u - u_i2;
+    const float dxm = rof_mm(nx0, nx1), dym = rof_mm(ny0, ny1);
+    RofD d;
+    if (ND == 3) {
+        const float nz1 = u_k1 - u, nz0 = u - u_k2;
+        const float dzm = rof_mm(nz0, nz1);
+        d.d1 = rof_norm(nx1, nx1 * nx1, dym, dzm);
+        d.d2 = rof_norm(ny1, dxm, ny1 * ny1, dzm);
+        d.d3 = rof_norm(nz1, dxm, dym, nz1 * nz1);
+    } else {
+        d.d1 = rof_norm(nx1, nx1 * nx1, dym, 0.0f);
+        d.d2 = rof_norm(ny1, dxm, ny1 * ny1, 0.0f);
+        d.d3 = 0.0f;
+    }
+    if (HALF) {
+        d.d1 = DualIO<__half>::rt(d.d1); d.d2 = DualIO<__half>::rt(d.d2); d.d3 = DualIO<__half>::rt(d.d3);
+    }
+    return d;
+}
+
+template <int ND, bool HALF, int RY, int WX, int WY>
+__global__ __launch_bounds__(64 * WX * WY) void rof_zmarch_kernel(RofArgs a, int gx, int gy, int gy_per_xcd, int zchunk)
+{
+    int j = (int)blockIdx.x >> 3;
+    const int xcd = (int)blockIdx.x & 7;
+    const int xb = j % gx;
+    j /= gx;
+    const int yb = xcd * gy_per_xcd + (j % gy_per_xcd);
+    const int chunk = j / gy_per_xcd;
+    if (yb >= gy) return;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int xs = xb * WX + (wave % WX);
+    const int x = xs * 60 - 2 + lane;
+    const int y0 = (yb * WY + (wave / WX)) * RY;
+    const int dx = a.dx, dy = a.dy, dz = a.planes;
+    const int zc0 = a.out_begin + chunk * zchunk;
+    const int zc1 = min(zc0 + zchunk, a.out_end);
+    if (zc0 >= zc1) return;
+
+    const size_t sz = (size_t)dx * dy;
+    const bool x_first = (x == 0), x_last = (x == dx - 1);
+    const bool emit_lane = (lane >= 2) && (lane <= 61) && (x < dx);
+    const int xc = min(max(x, 0), dx - 1);
+    unsigned off[RY + 3];  // rows -2..RY, index r+2
+#pragma unroll
+    for (int r = -2; r <= RY; ++r) off[r + 2] = (unsigned)(min(max(y0 + r, 0), dy - 1) * dx + xc) * 4u;
+    auto ldf = [](const float *base, unsigned boff) { return *(const float *)((const char *)base + boff); };
+
+    float Up[RY + 3], Uc[RY + 3], Un[RY + 3], carry3[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) carry3[r] = 0.0f;
+
+    // D of one plane for rows -1..RY-1 (index r+1) from the three U planes
+    auto eval_plane = [&](const float (&lo)[RY + 3], const float (&mid)[RY + 3], const float (&hi)[RY + 3], bool k_first,
+                          bool k_last, RofD (&D)[RY + 1]) {
+#pragma unroll
+        for (int r = -1; r < RY; ++r) {
+            const int y = y0 + r;
+            const float u = mid[r + 2];
+            const float ul = __shfl_up(u, 1, 64), ur = __shfl_down(u, 1, 64);
+            const float u_i1 = x_last ? ul : ur;
+            const float u_i2 = x_first ? ur : ul;
+            const float u_j1 = (y == dy - 1) ? mid[r + 1] : mid[r + 3];
+            const float u_j2 = (y == 0) ? mid[r + 3] : mid[r + 1];
+            const float u_k1 = k_last ? lo[r + 2] : hi[r + 2];
+            const float u_k2 = k_first ? hi[r + 2] : lo[r + 2];
+            D[r + 1] = rof_eval<ND, HALF>(u, u_i1, u_i2, u_j1, u_j2, u_k1, u_k2);
+        }
+    };
+
+    const int zstart = (ND == 3 && zc0 > 0) ? zc0 - 1 : zc0;  // warm-up plane builds the carried D3
+    {
+        const float *uc = a.u_in + sz * zstart;
+        const float *up = a.u_in + sz * max(zstart - 1, 0);
+#pragma unroll
+        for (int r = 0; r < RY + 3; ++r) { Uc[r] = ldf(uc, off[r]); Up[r] = (ND == 3) ? ldf(up, off[r]) : 0.0f; }
+    }
+
+    for (int t = zstart; t < zc1; ++t) {
+        __syncthreads();  // lockstep
+        const bool k_first = (t == 0) && a.first_is_edge;
+        const bool k_last = (t == dz - 1) && a.last_is_edge;
+        float In[RY];
+        if (ND == 3) {
+            const float *un = a.u_in + sz * min(t + 1, dz - 1);
+#pragma unroll
+            for (int r = 0; r < RY + 3; ++r) Un[r] = ldf(un, off[r]);
+        }
+        {
+            const float *ip = a.in + sz * t;
+#pragma unroll
+            for (int r = 0; r < RY; ++r) In[r] = ldf(ip, off[r + 2]);
+        }
+        RofD D[RY + 1];
+        eval_plane(Up, Uc, Un, k_first, k_last, D);
+        float d3_ahead[RY];
+#pragma unroll
+        for (int r = 0; r < RY; ++r) d3_ahead[r] = 0.0f;
+        if (ND == 3 && k_first) {
+            // global first plane: the backward z difference reflects to D3 of plane 1, which needs U of plane 2
+            float U2[RY + 3];
+            const float *u2 = a.u_in + sz * min(2, dz - 1);
+#pragma unroll
+            for (int r = 0; r < RY + 3; ++r) U2[r] = ldf(u2, off[r]);
+            RofD D1p[RY + 1];
+            eval_plane(Uc, Un, U2, false, (1 == dz - 1) && a.last_is_edge, D1p);
+#pragma unroll
+            for (int r = 0; r < RY; ++r) d3_ahead[r] = D1p[r + 1].d3;
+        }
+        const bool emit_plane = (t >= zc0);
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const int y = y0 + r;
+            // D1 of the reflected backward row (y-1, or y+1 at y == 0); D2 of the reflected backward lane
+            const float d1b = (y == 0) ? D[r + 2 <= RY ? r + 2 : RY].d1 : D[r].d1;
+            const float d2l = __shfl_up(D[r + 1].d2, 1, 64), d2r = __shfl_down(D[r + 1].d2, 1, 64);
+            const float d2b = x_first ? d2r : d2l;
+            float dv = (D[r + 1].d1 - d1b) + (D[r + 1].d2 - d2b);
+            if (ND == 3) {
+                const float d3b = k_first ? d3_ahead[r] : carry3[r];
+                dv = dv + (D[r + 1].d3 - d3b);
+                carry3[r] = D[r + 1].d3;
+            }
+            const float u = Uc[r + 2];
+            const float tt = fmaf(a.lambda, dv, -(u - In[r]));
+            const float uo = fmaf(a.tau, tt, u);
+            if (emit_plane && emit_lane && y < dy) *(float *)((char *)(a.u_out + sz * t) + off[r + 2]) = uo;
+        }
+        if (ND == 3) {
+#pragma unroll
+            for (int r = 0; r < RY + 3; ++r) { Up[r] = Uc[r]; Uc[r] = Un[r]; }
+        }
+    }
+}
+
+template <int ND, bool HALF, int RY, int WX, int WY>
+static int rof_zmarch_launch(const RofArgs &a, hipStream_t st)
+{
+    const int nout = a.out_end - a.out_begin;
+    const int gx = ceil_div(ceil_div(a.dx, 60), WX), gy = ceil_div(a.dy, WY * RY);
+    const int gy_per_xcd = ceil_div(gy, 8);
+    int chunks = 1;
+    if (ND == 3) {
+        const long waves_xy = (long)gx * gy * WX * WY;
+        chunks = (int)((256L * 4 * 32 + waves_xy - 1) / waves_xy);
+        const int max_chunks = ceil_div(nout, 32);
+        if (chunks > max_chunks) chunks = max_chunks;
+        if (chunks < 1) chunks = 1;
+    }
+    const int zchunk = ceil_div(nout, chunks);
+    chunks = ceil_div(nout, zchunk);
+    const long blocks = 8L * gx * gy_per_xcd * chunks;
+    if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one ROF_TV launch");
+    rof_zmarch_kernel<ND, HALF, RY, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd, zchunk);
+    return TOMO_OK;
+}

@@ -397,10 +397,29 @@ __global__ __launch_bounds__(256) void rof_pervoxel_kernel(RofArgs a)
     a.u_out[idx] = fmaf(a.tau, t, u);
 }
 
+#include "rof_zmarch.inl"
+
+template <int ND, bool HALF>
+int rof_zmarch_dispatch(const RofArgs &a, int variant, hipStream_t st)
+{
+    int rc = (variant == 2)   ? rof_zmarch_launch<ND, HALF, 4, 4, 2>(a, st)
+             : (variant == 3) ? rof_zmarch_launch<ND, HALF, 8, 4, 1>(a, st)
+             : (variant == 4) ? rof_zmarch_launch<ND, HALF, 4, 2, 2>(a, st)
+                              : rof_zmarch_launch<ND, HALF, 8, 2, 2>(a, st);
+    if (rc != TOMO_OK) return rc;
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
 int rof_iter(const RofArgs &a, int nd, int half, hipStream_t st)
 {
     const int nout = a.out_end - a.out_begin;
     if (nout <= 0) return TOMO_OK;
+    if (g_variant_roftv != 1) {  // z-march (default); variant 1 = per-voxel kernel below
+        const int v = g_variant_roftv;
+        if (nd == 3) return half ? rof_zmarch_dispatch<3, true>(a, v, st) : rof_zmarch_dispatch<3, false>(a, v, st);
+        return half ? rof_zmarch_dispatch<2, true>(a, v, st) : rof_zmarch_dispatch<2, false>(a, v, st);
+    }
     dim3 grid(ceil_div(a.dx, 256), a.dy, nout);
     if (nd == 3) {
         if (half) rof_pervoxel_kernel<3, true><<<grid, 256, 0, st>>>(a);

@@ -55,8 +55,11 @@ for variant in (0, 1):
         bpv = 24 if half else 36
         print(f"PD_TV v{variant} half={int(half)}: {ms:8.3f} ms/iter  {bpv*V/ms/1e6:8.1f} GB/s alg")
 ops.set_variant("pdtv", 0)
-ms = timeit(lambda: ROF_TV_cupy(vol, 0.01, IT, 0.001, 0, False, out=out_v)) / IT
-print(f"ROF_TV        : {ms:8.3f} ms/iter  {12*V/ms/1e6:8.1f} GB/s alg")
+for variant in (0, 2, 3, 4, 1):
+    ops.set_variant("roftv", variant)
+    ms = timeit(lambda: ROF_TV_cupy(vol, 0.01, IT, 0.001, 0, False, out=out_v)) / IT
+    print(f"ROF_TV v{variant}     : {ms:8.3f} ms/iter  {12*V/ms/1e6:8.1f} GB/s alg")
+ops.set_variant("roftv", 0)
 x2 = torch.rand_like(vol)
 ms = timeit(lambda: ops.momentum(vol, x2, out_v, 0.5))
 print(f"momentum      : {ms:8.3f} ms  {12*V/ms/1e6:8.1f} GB/s")
