@@ -205,6 +205,13 @@ int tomo_roftv_iter_slab(int device, const float *in_dev, const float *u_in_dev,
                          int dx, int dy, int nz_local, int lo_planes, int hi_planes,
                          float lambda, float tau, int half, void *stream);
 
+/* ---------------------------------------------------------------- FBP filter
+ * tomo_fbp_filter replaces _filtersinc3D_cupy (tomobar/fourier.py:26-78) and generate_filtersinc
+ * (cuda_kernels/generate_filtersync.cu:5-82): every row of `rows` x `nu` float32 values is replaced, in place, by
+ * irfft( rfft(row) * f ), f = fftshift-ed half-spectrum sinc-ramp of cut-off `cutoff`, unnormalised transforms with
+ * `multiplier` (= 1/angles/nu in RecToolsDIRCuPy.FBP) folded into f.  Batched hipFFT; synchronises the stream. */
+int tomo_fbp_filter(int device, float *data_dev, size_t rows, int nu, float cutoff, float multiplier, void *stream);
+
 /* kernel-variant selector for A/B measurement: name in {"bp","fp","pdtv","roftv"}; variant 0 = default */
 int tomo_set_variant(const char *kernel, int variant);
 

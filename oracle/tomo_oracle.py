@@ -388,6 +388,34 @@ def admm(P: Projector, b, iterations, lipschitz_const, rho=1.0, relax=1.6, nonne
     return x
 
 
+# ------------------------------------------------------------------ FBP
+def sinc_filter(n, cutoff, multiplier):
+    """Half-spectrum, fftshift-ed sinc-ramp filter in float32: generate_filtersync.cu:5-82 / methodsDIR.py:295-312."""
+    a = np.float32(cutoff)
+    w = (np.float32(-np.pi) + np.arange(n, dtype=np.float32) * np.float32(2 * np.pi / n)).astype(np.float32)
+    rd = (a * w / np.float32(2.0)).astype(np.float32)
+    rn2 = np.sin(rd).astype(np.float32)
+    dot = np.float32(np.sum((rn2 * rd / np.float32(np.sum(rd * rd, dtype=np.float32))).astype(np.float32), dtype=np.float32))
+    r = (np.abs(np.float32(2.0) / a * rn2) * dot * dot).astype(np.float32)
+    full = np.zeros(n, np.float32)
+    full[(np.arange(n) + n // 2) % n] = r
+    return (full[:n // 2 + 1] * np.float32(multiplier)).astype(np.float32)
+
+
+def fbp_filter(data, cutoff=0.35):
+    """fourier.py:26-78 on [angles, detY, detX] float32 data: rfft(detX) * filter, unnormalised irfft."""
+    import scipy.fft
+    na, nz, nu = data.shape
+    f = sinc_filter(nu, cutoff, 1.0 / na / nu)
+    spec = scipy.fft.rfft(data.astype(np.float32), axis=-1) * f
+    return (scipy.fft.irfft(spec, nu, axis=-1) * nu).astype(np.float32)  # scipy normalises the inverse by 1/n
+
+
+def fbp(P: Projector, data, cutoff=0.35):
+    """methodsDIR_CuPy.py:114-150: filter, bring to [detY, angles, detX], back project."""
+    return P.bp(np.ascontiguousarray(np.swapaxes(fbp_filter(data, cutoff), 0, 1)))
+
+
 # ------------------------------------------------------------------ glue (suppTools.py)
 def pad_detector(b, pad):
     """suppTools.py:425-459 (edge padding of detX)"""

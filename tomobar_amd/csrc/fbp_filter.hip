@@ -1,0 +1,103 @@
+// Sinc-ramp filtering of projection rows for FBP.
+// Replaces tomobar/fourier.py:26-78 (_filtersinc3D_cupy: rfft along detX, multiply by the filter built by
+// cuda_kernels/generate_filtersync.cu:5-82, unnormalised irfft with the 1/n and 1/Na factors folded into the filter).
+// The FFTs are plain batched 1D real transforms -> hipFFT (library call, like the reference's cuFFT via CuPy); the filter
+// table is tiny and is built on the host with the reference kernel's float32 formulas.
+#include "tomo_common.h"
+
+#include <hipfft/hipfft.h>
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+#define TOMO_FFT(expr)                                                                              \
+    do {                                                                                            \
+        hipfftResult r_ = (expr);                                                                   \
+        if (r_ != HIPFFT_SUCCESS) return tomo_fail(TOMO_E_RUNTIME, "%s failed: hipfft status %d", #expr, (int)r_); \
+    } while (0)
+
+__global__ __launch_bounds__(256) void apply_filter_kernel(float2 *spec, const float *__restrict__ f, size_t rows, int nh)
+{
+    const size_t total = rows * (size_t)nh;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const float g = f[i % nh];
+        float2 v = spec[i];
+        v.x *= g;
+        v.y *= g;
+        spec[i] = v;
+    }
+}
+
+// half-spectrum filter, fftshift-ed: f[(i + n/2) % n] = |2/a sin(a w_i/2)| * (sum sin(a w/2)(a w/2) / sum (a w/2)^2)^2 * mult
+std::vector<float> make_filter(int n, float a, float mult)
+{
+    const float pi = 3.1415926535897932384626433832795f;
+    const float dw = 2 * pi / n;
+    float sum = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        const float w = -pi + i * dw;
+        const float rd = a * w / 2.0f;
+        sum += rd * rd;
+    }
+    float dot = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        const float w = -pi + i * dw;
+        const float rd = a * w / 2.0f;
+        dot += sinf(rd) * rd / sum;
+    }
+    const float dot2 = dot * dot;
+    std::vector<float> f(n / 2 + 1, 0.0f);
+    for (int i = 0; i < n; ++i) {
+        const int out = (i + n / 2) % n;
+        if (out >= n / 2 + 1) continue;
+        const float w = -pi + i * dw;
+        const float rd = a * w / 2.0f;
+        const float rn1 = (float)std::fabs(2.0 / (double)a * (double)sinf(rd));
+        f[out] = rn1 * dot2 * mult;
+    }
+    return f;
+}
+
+}  // namespace
+
+extern "C" int tomo_fbp_filter(int device, float *data_dev, size_t rows, int nu, float cutoff, float multiplier,
+                               void *stream)
+{
+    TOMO_REQUIRE(device >= 0 && data_dev != nullptr && nu >= 2 && cutoff > 0.0f, "bad FBP filter arguments");
+    if (rows == 0) return TOMO_OK;
+    TOMO_REQUIRE(rows <= 0x7fffffffULL, "too many projection rows for one hipFFT plan");
+    TOMO_HIP(hipSetDevice(device));
+    hipStream_t st = as_stream(stream);
+    const int nh = nu / 2 + 1;
+    const size_t spec_bytes = rows * (size_t)nh * sizeof(float2);
+    const size_t filt_bytes = ((size_t)nh * sizeof(float) + 255) / 256 * 256;
+    void *base = nullptr;
+    int rc = tomo_arena_get(device, spec_bytes + filt_bytes, &base);
+    if (rc != TOMO_OK) return rc;
+    float2 *spec = (float2 *)base;
+    float *filt = (float *)((char *)base + spec_bytes);
+    const std::vector<float> f = make_filter(nu, cutoff, multiplier);
+    TOMO_HIP(hipMemcpyAsync(filt, f.data(), (size_t)nh * sizeof(float), hipMemcpyHostToDevice, st));
+    TOMO_HIP(hipStreamSynchronize(st));  // f is a stack-owned host buffer
+
+    hipfftHandle fwd = 0, inv = 0;
+    int n[1] = {nu};
+    TOMO_FFT(hipfftPlanMany(&fwd, 1, n, nullptr, 1, nu, nullptr, 1, nh, HIPFFT_R2C, (int)rows));
+    TOMO_FFT(hipfftPlanMany(&inv, 1, n, nullptr, 1, nh, nullptr, 1, nu, HIPFFT_C2R, (int)rows));
+    TOMO_FFT(hipfftSetStream(fwd, st));
+    TOMO_FFT(hipfftSetStream(inv, st));
+    TOMO_FFT(hipfftExecR2C(fwd, data_dev, (hipfftComplex *)spec));
+    size_t total = rows * (size_t)nh;
+    size_t grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    apply_filter_kernel<<<(unsigned)grid, 256, 0, st>>>(spec, filt, rows, nh);
+    TOMO_LAUNCH_CHECK();
+    TOMO_FFT(hipfftExecC2R(inv, (hipfftComplex *)spec, data_dev));
+    TOMO_HIP(hipStreamSynchronize(st));  // plans are destroyed below
+    (void)hipfftDestroy(fwd);
+    (void)hipfftDestroy(inv);
+    return TOMO_OK;
+}
