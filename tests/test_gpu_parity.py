@@ -95,6 +95,22 @@ def test_forward_projection_vs_oracle(oracle, ops, g, variant):
         assert np.array_equal(got, want), f"FP not bit-identical: max abs {np.abs(got - want).max()}"
 
 
+@pytest.mark.parametrize("n,na,os_n", [(280, 180, 5), (256, 180, None), (300, 60, None), (280, 90, 3)])
+@pytest.mark.parametrize("variant", [0, 2])
+def test_forward_projection_oblique_windows(oracle, ops, n, na, os_n, variant):
+    """Regression: detector tiles whose staged row window is clipped by the volume at both ends of the march but not
+    in the middle (oblique rays at the detector edge) -- the LDS pitch must come from the unclipped window."""
+    from tomobar_amd.projector import HipTools3D
+    ops.set_variant("fp", variant)
+    angles = np.linspace(0, np.pi, na, endpoint=False)
+    H = HipTools3D(n, 0, 4, angles, 0.0, n, "gpu", 0, os_n)
+    P = oracle.Projector(4, n, n, angles, 0.0, os_n or 1)
+    vol = np.random.default_rng(4).standard_normal((4, n, n)).astype(np.float32)
+    for s in (range(os_n) if os_n else [None]):
+        got = host(H.forward(dev(vol), s))
+        assert np.array_equal(got, P.fp(vol, s)), (n, na, s)
+
+
 def test_lerp8_mode_and_reference_literals(oracle, ops):
     """tests/test_RecToolsDIRCuPy.py:671-694 of the reference: ones(128,160,160) -> min 67.27458 max 225.27428."""
     from tomobar_amd.projector import HipTools3D

@@ -192,6 +192,26 @@ def test_simple_iterative_methods_vs_oracle(oracle, geom):
     assert rel(got, x.reshape(nz, n, n)) < 1e-4  # inner products accumulate in a different order
 
 
+def test_medium_size_fista_os_pdtv_pad_vs_oracle(oracle):
+    """A geometry large enough to have several detector / voxel tiles, clipped windows and a padded detector:
+    FISTA-OS + PD_TV on the MI355X must equal the oracle's run bit for bit."""
+    from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    nz, det, pad, na, os_n = 6, 200, 20, 90, 5
+    n = det + 2 * pad
+    angles = np.linspace(0, np.pi, na, endpoint=False)
+    sino = oracle.shepp_logan_sino(det, nz, det, angles) / det
+    sino += 0.01 * np.random.default_rng(0).standard_normal(sino.shape).astype(np.float32)
+    P = oracle.Projector(nz, n, n, angles, 0.0, os_n)
+    Lc = oracle.power_method(P, np.random.default_rng(1).standard_normal((nz, n, n)).astype(np.float32))
+    reg = {"method": "PD_TV", "regul_param": 0.002, "iterations": 7, "methodTV": 0, "PD_LipschitzConstant": 12.0}
+    want = oracle.crop_recon(oracle.fista(P, oracle.pad_detector(sino, pad), 2, Lc, True, reg), det)
+    rt = RecToolsIRCuPy(det, pad, nz, 0.0, angles, det, 0, os_n)
+    rec = rt.FISTA({"projection_data": sino, "data_axes_labels_order": ["detY", "angles", "detX"]},
+                   {"iterations": 2, "lipschitz_const": Lc, "nonnegativity": True},
+                   {"method": "PD_TV", "regul_param": 0.002, "iterations": 7})
+    assert np.array_equal(host(rec), want), rel(host(rec), want)
+
+
 def test_dir_forwproj_backproj(oracle, geom):
     from tomobar_amd.methodsDIR_CuPy import RecToolsDIRCuPy
     rt = RecToolsDIRCuPy(geom["n"], 0, geom["nz"], 0.0, geom["angles"], geom["n"], device_projector=0)

@@ -188,28 +188,30 @@ __global__ __launch_bounds__(256) void fp_tiled_kernel(FpTiledArgs a)
 // Upper bound (host, same float arithmetic as the kernel) of the staged window width over all groups / tiles / rows.
 // The width is a max of affine functions of the row index minus a min of affine functions, hence convex: its maximum
 // over the march is attained at the first or the last row.
-static int fp_window_bound(const tomo_angle_t *tab, const int *order, int n_class, int n, int nu)
+static int fp_window_bound(const tomo_angle_t *tab, const int *order, int n_class, int n, int nu, int tile = 256,
+                           int group = FP_A)
 {
     const float half_n = 0.5f * (float)n - 0.5f, half_u = 0.5f * (float)nu - 0.5f;
     int bound = 2;
-    const int nut = ceil_div(nu, 256);
-    for (int g = 0; g * FP_A < n_class; ++g) {
-        const int ng = std::min(FP_A, n_class - g * FP_A);
+    const int nut = ceil_div(nu, tile);
+    for (int g = 0; g * group < n_class; ++g) {
+        const int ng = std::min(group, n_class - g * group);
         for (int ut = 0; ut < nut; ++ut) {
             for (int e = 0; e < 2; ++e) {
                 const float kw = (float)(e ? n - 1 : 0) - half_n;
                 float fmin = 3.0e38f, fmax = -3.0e38f;
                 for (int i = 0; i < ng; ++i) {
-                    const tomo_angle_t &t = tab[order[g * FP_A + i]];
-                    const float o0 = std::fmaf(((float)(ut * 256) - half_u) + t.cor, t.inv, half_n);
-                    const float o1 = std::fmaf(((float)(ut * 256 + 255) - half_u) + t.cor, t.inv, half_n);
+                    const tomo_angle_t &t = tab[order[g * group + i]];
+                    const float o0 = std::fmaf(((float)(ut * tile) - half_u) + t.cor, t.inv, half_n);
+                    const float o1 = std::fmaf(((float)(ut * tile + tile - 1) - half_u) + t.cor, t.inv, half_n);
                     const float f0 = std::fmaf(kw, t.slope, o0), f1 = std::fmaf(kw, t.slope, o1);
                     fmin = std::min(fmin, std::min(f0, f1));
                     fmax = std::max(fmax, std::max(f0, f1));
                 }
-                const int lo = (int)std::min(std::max(std::floor(fmin), -2.0f), (float)n);
-                const int hi = (int)std::min(std::max(std::floor(fmax) + 1.0f, -1.0f), (float)(n + 1));
-                bound = std::max(bound, hi - lo + 1);
+                // UNCLIPPED width: only that is convex in the row index (clipping to the volume can make the end rows
+                // narrow while a middle row, fully inside the volume, is wide); the clip is applied once at the end
+                const double wdt = (double)std::floor(fmax) + 1.0 - (double)std::floor(fmin) + 1.0;
+                bound = std::max(bound, (int)std::min(wdt, (double)n + 4.0));
             }
         }
     }
@@ -218,8 +220,12 @@ static int fp_window_bound(const tomo_angle_t *tab, const int *order, int n_clas
 
 // ---- synchronous (non-pipelined) form: stage kc rows, barrier, sample, barrier.  Small LDS footprint, so many
 //      workgroups per CU hide the staging latency instead of a register prefetch.  Variant 2 (A/B measurement).
-template <bool LERP8, bool RESID>
-__global__ __launch_bounds__(256) void fp_tiled_sync_kernel(FpTiledArgs a, int kc)
+// BT = workgroup size = detector pixels per workgroup (256 / 512 / 1024): a wider detector tile amortises the part of
+// the window that comes from the angular spread of the group over more rays.
+// A = angles sampled per staged row (8, or 20 when the angular spread of a subset makes the window a whole row anyway:
+// more angles per staged byte and more sampling work per barrier)
+template <bool LERP8, bool RESID, int BT, int A>
+__global__ __launch_bounds__(BT) void fp_tiled_sync_kernel(FpTiledArgs a, int kc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fp_smem[];
     float4 *tile = reinterpret_cast<float4 *>(fp_smem);
@@ -230,13 +236,13 @@ __global__ __launch_bounds__(256) void fp_tiled_sync_kernel(FpTiledArgs a, int k
     if (zb >= a.nzb) return;
     const int rest = q % per_zb;
     const int ut = rest % a.nut, g = rest / a.nut;
-    const int z0 = zb * 4, u0 = ut * 256, tid = (int)threadIdx.x, iu = u0 + tid, n = a.n;
-    const int ng = min(FP_A, a.n_class - g * FP_A);
-    const int *ord = a.order + g * FP_A;
+    const int z0 = zb * 4, u0 = ut * BT, tid = (int)threadIdx.x, iu = u0 + tid, n = a.n;
+    const int ng = min(A, a.n_class - g * A);
+    const int *ord = a.order + g * A;
     const float half_n = 0.5f * (float)n - 0.5f, half_u = 0.5f * (float)a.nu - 0.5f;
-    float offs[FP_A], slope[FP_A], acc[FP_A][4];
+    float offs[A], slope[A], acc[A][4];
 #pragma unroll
-    for (int i = 0; i < FP_A; ++i) {
+    for (int i = 0; i < A; ++i) {
         const tomo_angle_t t = a.tab[ord[i < ng ? i : 0]];
         offs[i] = fmaf(((float)iu - half_u) + t.cor, t.inv, half_n);
         slope[i] = t.slope;
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256) void fp_tiled_sync_kernel(FpTiledArgs a, int k
             for (int i = 0; i < ng; ++i) {
                 const tomo_angle_t t = a.tab[ord[i]];
                 const float o0 = fmaf(((float)u0 - half_u) + t.cor, t.inv, half_n);
-                const float o1 = fmaf(((float)(u0 + 255) - half_u) + t.cor, t.inv, half_n);
+                const float o1 = fmaf(((float)(u0 + BT - 1) - half_u) + t.cor, t.inv, half_n);
                 const float f0 = fmaf(kw, t.slope, o0), f1 = fmaf(kw, t.slope, o1);
                 fmin = fminf(fmin, fminf(f0, f1));
                 fmax = fmaxf(fmax, fmaxf(f0, f1));
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256) void fp_tiled_sync_kernel(FpTiledArgs a, int k
             const int lo = xlo_s[r], wid = wid_s[r];
             const unsigned rowoff = (unsigned)(k0 + r) * (unsigned)n;
             float4 *trow = tile + (size_t)r * a.wpitch;
-            for (int j = tid; j < wid; j += 256) {
+            for (int j = tid; j < wid; j += BT) {
                 const int x = lo + j;
                 const unsigned mk = (x >= 0 && x < n) ? 0xffffffffu : 0u;
                 const unsigned off = rowoff + (unsigned)min(max(x, 0), n - 1);
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(256) void fp_tiled_sync_kernel(FpTiledArgs a, int k
             const int lo = xlo_s[r];
             const float4 *trow = tile + (size_t)r * a.wpitch;
 #pragma unroll
-            for (int i = 0; i < FP_A; ++i) {
+            for (int i = 0; i < A; ++i) {
                 const float f = fmaf(kw, slope[i], offs[i]);
                 const float fl = floorf(f);
                 const float w = lerp_w<LERP8>(f, fl), omw = 1.0f - w;
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256) void fp_tiled_sync_kernel(FpTiledArgs a, int k
     }
     if (iu >= a.nu) return;
 #pragma unroll
-    for (int i = 0; i < FP_A; ++i) {
+    for (int i = 0; i < A; ++i) {
         if (i >= ng) break;
         const int k_a = ord[i];
         const tomo_angle_t t = a.tab[k_a];

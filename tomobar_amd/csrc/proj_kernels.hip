@@ -362,7 +362,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
     bool tiled = (g_variant_fp != 1);
     if (tiled) {
         size_t off = s.table_offset;
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < 4; ++c) {
             if (s.n_class[c] > 0 && s.wbound[c] < 0)
                 s.wbound[c] = fp_window_bound(ctx->host_table.data() + s.table_offset, ctx->host_fp_order.data() + off,
                                               s.n_class[c], ctx->n, ctx->nu);
@@ -372,11 +372,11 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
     }
     if (tiled) {
         size_t order_off = s.table_offset;
-        for (int c = 0; c < 2; ++c) {  // one launch per stepping class (class 1 reads the transposed copy)
+        for (int c = 0; c < 4; ++c) {  // one launch per stepping class (x-stepping classes read the transposed copy)
             const int nc = s.n_class[c];
             if (nc > 0) {
                 FpTiledArgs t;
-                t.src = c ? a.volT : a.vol;
+                t.src = (c >> 1) ? a.volT : a.vol;
                 t.tab = a.tab;
                 t.order = ctx->dev_fp_order + order_off;
                 t.n_class = nc;
@@ -395,14 +395,43 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 // windows (ordered subsets spread the angles of a group) run the synchronous form, whose small LDS
                 // footprint lets many workgroups per CU hide the staging latency.  Measured on MI355X:
                 // 512^3 x 360 angles 8.4 ms (pipelined) vs 10.0 (sync); 1024^3 x 75 angles 22 ms (sync).
-                if (g_variant_fp == 2 || t.wpitch > 512) {
-                    static const int lds_budget = getenv("TOMO_FP_LDS") ? atoi(getenv("TOMO_FP_LDS")) : 24000;
+                static const int pipe_max = getenv("TOMO_FP_PIPE_MAX") ? atoi(getenv("TOMO_FP_PIPE_MAX")) : 512;
+                if (g_variant_fp == 2 || t.wpitch > std::min(pipe_max, FP_MAX_WPITCH)) {
+                    static const int lds_budget = getenv("TOMO_FP_LDS") ? atoi(getenv("TOMO_FP_LDS")) : 40000;
+                    // wide windows: a wider detector tile (more threads per workgroup) shares the spread-induced part
+                    static const int bt_env = getenv("TOMO_FP_BT") ? atoi(getenv("TOMO_FP_BT")) : 0;
+                    static const int ga_env = getenv("TOMO_FP_A") ? atoi(getenv("TOMO_FP_A")) : 0;
+                    int bt = bt_env ? bt_env : 256;
+                    if (bt != 256 && bt != 512 && bt != 1024) bt = 256;
+                    // wide windows (angular spread of an ordered subset): sample 20 angles per staged row
+                    // measured (1024^3 x 75): 8 angles per row 22.6 ms; 20 angles 36-65 ms (register file: the
+                    // 80 accumulators + prefetch no longer stay in VGPRs)
+                    const int ga = (ga_env == 8 || ga_env == 20) ? ga_env : 8;
+                    if (bt > 256 || ga != FP_A) {
+                        t.wpitch = fp_window_bound(ctx->host_table.data() + s.table_offset,
+                                                   ctx->host_fp_order.data() + order_off, nc, ctx->n, ctx->nu, bt, ga);
+                        t.nut = ceil_div(a.nu, bt);
+                        t.ngroups = ceil_div(nc, ga);
+                    }
+                    const long blocks_s = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
                     const int kcs = std::max(1, std::min(8, lds_budget / (t.wpitch * 16)));
                     const size_t sm = (size_t)kcs * t.wpitch * 16;
-                    if (b) { if (l8) fp_tiled_sync_kernel<true, true><<<(unsigned)blocks, 256, sm, st>>>(t, kcs);
-                             else fp_tiled_sync_kernel<false, true><<<(unsigned)blocks, 256, sm, st>>>(t, kcs); }
-                    else   { if (l8) fp_tiled_sync_kernel<true, false><<<(unsigned)blocks, 256, sm, st>>>(t, kcs);
-                             else fp_tiled_sync_kernel<false, false><<<(unsigned)blocks, 256, sm, st>>>(t, kcs); }
+                    TOMO_REQUIRE(sm <= 64 * 1024, "forward-projection window does not fit in LDS");
+#define FP_SYNC_LAUNCH(L8, RES)                                                                                   \
+    do {                                                                                                          \
+        if (ga == 20) {                                                                                           \
+            if (bt == 256) fp_tiled_sync_kernel<L8, RES, 256, 20><<<(unsigned)blocks_s, 256, sm, st>>>(t, kcs);   \
+            else if (bt == 512) fp_tiled_sync_kernel<L8, RES, 512, 20><<<(unsigned)blocks_s, 512, sm, st>>>(t, kcs); \
+            else fp_tiled_sync_kernel<L8, RES, 1024, 20><<<(unsigned)blocks_s, 1024, sm, st>>>(t, kcs);           \
+        } else {                                                                                                  \
+            if (bt == 256) fp_tiled_sync_kernel<L8, RES, 256, 8><<<(unsigned)blocks_s, 256, sm, st>>>(t, kcs);    \
+            else if (bt == 512) fp_tiled_sync_kernel<L8, RES, 512, 8><<<(unsigned)blocks_s, 512, sm, st>>>(t, kcs); \
+            else fp_tiled_sync_kernel<L8, RES, 1024, 8><<<(unsigned)blocks_s, 1024, sm, st>>>(t, kcs);            \
+        }                                                                                                         \
+    } while (0)
+                    if (b) { if (l8) FP_SYNC_LAUNCH(true, true); else FP_SYNC_LAUNCH(false, true); }
+                    else   { if (l8) FP_SYNC_LAUNCH(true, false); else FP_SYNC_LAUNCH(false, false); }
+#undef FP_SYNC_LAUNCH
                     TOMO_LAUNCH_CHECK();
                     order_off += nc;
                     continue;

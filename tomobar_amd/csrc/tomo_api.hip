@@ -116,9 +116,9 @@ extern "C" int tomo_ctx_create(int device, int nz, int n, int nu, int na, const 
         // FP order table: class 0 (y-stepping) then class 1 (x-stepping), each sorted by the march slope so that the
         // angles one workgroup handles together sample neighbouring parts of every volume row
         const tomo_angle_t *tab = ctx->host_table.data() + s.table_offset;
-        std::vector<int> order[2];
-        for (int i = 0; i < s.size; ++i) order[tab[i].dirx].push_back(i);
-        for (int c = 0; c < 2; ++c) {
+        std::vector<int> order[4];
+        for (int i = 0; i < s.size; ++i) order[2 * tab[i].dirx + (tab[i].inv < 0.0f ? 1 : 0)].push_back(i);
+        for (int c = 0; c < 4; ++c) {
             std::stable_sort(order[c].begin(), order[c].end(), [&](int p, int q) { return tab[p].slope < tab[q].slope; });
             s.n_class[c] = (int)order[c].size();
             ctx->host_fp_order.insert(ctx->host_fp_order.end(), order[c].begin(), order[c].end());

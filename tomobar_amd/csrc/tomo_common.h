@@ -40,8 +40,10 @@ struct tomo_subset {
     int n_dirx = 0;           // how many angles step along x (FP)
     // FP stepping classes: the order table lists the subset-local indices of the y-stepping angles (class 0)
     // followed by the x-stepping ones (class 1), each sorted by angle; wbound = cached LDS window bound (-1 = unset)
-    int n_class[2] = {0, 0};
-    int wbound[2] = {-1, -1};
+    // class = 2*dirx + (inv < 0): angles whose detector axis runs the opposite way along the interpolation axis
+    // (e.g. theta near 0 and near pi) sample opposite ends of a volume row and must not share a staged window
+    int n_class[4] = {0, 0, 0, 0};
+    int wbound[4] = {-1, -1, -1, -1};
 };
 
 struct tomo_ctx {

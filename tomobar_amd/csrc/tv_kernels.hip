@@ -18,6 +18,22 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------ helpers
+// One-lane wave shifts.  The z-march kernels only ever exchange with the neighbouring lane; __shfl_up/down(v, 1, 64)
+// lower to ds_bpermute_b32 (an LDS-pipe instruction with ~50+ cycles latency), the gfx9 DPP wave shifts are a single
+// VALU move.  Lane 0 (wave_prev) / lane 63 (wave_next) receive 0; those lanes are halo lanes whose shifted-in value is
+// never consumed.
+__device__ __forceinline__ float wave_prev(float v)  // lane i <- lane i-1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_next(float v)  // lane i <- lane i+1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+}
+#ifndef TOMO_TV_NO_DPP
+#define __shfl_up(v, d, w) wave_prev(v)
+#define __shfl_down(v, d, w) wave_next(v)
+#endif
 template <typename T> struct DualIO;
 template <> struct DualIO<float> {
     static __device__ __forceinline__ float ld(const float *p, size_t i) { return p[i]; }
