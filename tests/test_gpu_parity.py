@@ -63,7 +63,7 @@ def make_pair(oracle, g, flags=0):
 
 
 @pytest.mark.parametrize("g", GEOMS)
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_backprojection_vs_oracle(oracle, ops, g, variant):
     P, H = make_pair(oracle, g)
     ops.set_variant("bp", variant)
@@ -121,7 +121,7 @@ def test_lerp8_mode_and_reference_literals(oracle, ops):
     np.testing.assert_allclose(s.max(), 225.27428, rtol=2e-6)
     P = oracle.Projector(8, 160, 160, angles, flags=oracle.FLAG_LERP8)
     sino = np.random.default_rng(0).random((8, 180, 160)).astype(np.float32)
-    for v in (0, 1):
+    for v in (0, 1, 2):
         ops.set_variant("bp", v)
         assert rel(host(H.backward(dev(sino))), P.bp(sino)) < 1e-6
 
@@ -160,7 +160,7 @@ def test_fused_residual_and_gradient_steps(oracle, ops):
         r = (ax - b[:, idx]).astype(np.float32)
         grad = P.bp(r, s)
         linv, beta = np.float32(1 / 300.0), np.float32(0.37)
-        for variant in (0, 1):
+        for variant in (0, 1, 2):
             ops.set_variant("bp", variant)
             for nonneg in (False, True):
                 X = x - linv * grad

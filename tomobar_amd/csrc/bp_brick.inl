@@ -1,0 +1,172 @@
+// Back projector, "brick" variant (default).  Included inside the anonymous namespace of proj_kernels.hip.
+//
+// A 256-thread workgroup owns a 32(x) x 16(y) x 16(z) voxel brick; a thread owns two voxel columns (same x, rows four
+// apart) x 16 slices = 32 accumulators.  For every batch of 8 angles the part of the sinogram the brick can touch
+// (<= 31|cos| + 15|sin| + 2 < 38 detector samples per angle and slice) is staged in LDS as float4 over z, then every
+// tap is one ds_read_b128 serving 4 slices.  What the PMC counters said about the first tiled kernel (64 x 8 brick,
+// lanes along x; profiles/r1_bp_fp_pmc.txt) and what this kernel does about it:
+//   * half of its VALU instructions were staging (div/mod item decoding, 64-bit addresses, four guarded loads per
+//     item): here an item's LDS slot and global offset are loop invariants, loads are unconditional on clamped
+//     addresses (slices >= nz are fed by a valid slice and never stored), 5 items per thread instead of 9;
+//   * 28 % of its LDS cycles were bank conflicts: ds_read_b128 is served in 16-lane groups that are NOT contiguous
+//     ({0-3,12-15,20-27}, ...), so with lanes along x a group spans up to 27|cos| slots, more than the 16 slots of a
+//     bank row.  Here a wave is a 16(x) x 4(y) patch: every group spans <= 15|cos| + |sin| < 16 slots;
+//   * staging latency was exposed (stage, barrier, sample, barrier): here the loads of batch b+1 are in flight (held
+//     in registers) while batch b is sampled.
+// Accumulation order (angles ascending, tap 0 then tap 1, fmaf) is that of the oracle: results are bit-identical.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int BB_TX = 32, BB_TY = 16, BB_ZQ = 4, BB_AB = 8, BB_PITCH = 40;
+constexpr int BB_ITEMS = BB_AB * BB_ZQ * BB_PITCH / 256;  // 5 staging items per thread and batch
+static_assert(BB_AB * BB_ZQ * BB_PITCH == 256 * BB_ITEMS, "staging items must divide evenly");
+
+template <int EPI, bool LERP8>
+__global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
+{
+    __shared__ float4 tile2[2][BB_AB * BB_ZQ * BB_PITCH];  // double-buffered [angle][z-quad][u], 2 x 20 KiB
+    __shared__ int umin_s[3][BB_AB];  // three slots: a slow wave may still sample batch b-1 while batch b+1's window is written
+
+    // XCD-aware numbering: workgroup b lands on XCD b%8; give each XCD its own z-brick stream
+    const int ntiles = a.ntx * a.nty;
+    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+    const int zb = (q / ntiles) * 8 + xcd;
+    if (zb >= a.nzb) return;  // uniform for the workgroup
+    const int tq = q % ntiles;
+    const int tx0 = (tq % a.ntx) * BB_TX, ty0 = (tq / a.ntx) * BB_TY;
+    const int z0 = zb * (4 * BB_ZQ);
+
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ix = tx0 + (wave & 1) * 16 + (lane & 15);
+    const int iy0 = ty0 + (wave >> 1) * 8 + (lane >> 4);  // rows iy0 and iy0 + 4
+    const float half_n = 0.5f * (float)a.n - 0.5f, half_u = 0.5f * (float)a.nu - 0.5f;
+    const float xw = (float)ix - half_n;
+    const float yw0 = (float)iy0 - half_n, yw1 = (float)(iy0 + 4) - half_n;
+
+    // accumulators as explicit 2-vectors (slices 2h, 2h+1): one v_pk_fma_f32 per tap and slice pair.  Left to itself the
+    // SLP vectoriser pairs accumulators of DIFFERENT rows and pays ~35 v_mov per angle to assemble the operands.
+    v2f acc[2][2 * BB_ZQ];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 2 * BB_ZQ; ++j) acc[r][j] = v2f{0.0f, 0.0f};
+
+    // ---- loop-invariant part of the staging items: item = tid + 256 m  ->  (angle slot, z-quad, column)
+    const unsigned zstride = (unsigned)a.na * (unsigned)a.nu;  // elements; host guarantees 16 * zstride * 4 < 2^32
+    const int zlim = a.nz - 1 - z0;                            // last valid slice relative to z0 (>= 0)
+    const bool ragged = zlim < 4 * BB_ZQ - 1;                  // uniform: only the last z-brick
+    int it_aa[BB_ITEMS], it_j[BB_ITEMS];
+    unsigned it_off[BB_ITEMS];  // element offset of (slice z0 + 4 zq, angle slot, column 0) from the batch base
+#pragma unroll
+    for (int m = 0; m < BB_ITEMS; ++m) {
+        const int item = tid + 256 * m;
+        it_j[m] = item % BB_PITCH;
+        const int zq = (item / BB_PITCH) % BB_ZQ;
+        it_aa[m] = item / (BB_PITCH * BB_ZQ);
+        it_off[m] = (unsigned)min(4 * zq, zlim) * zstride + (unsigned)it_aa[m] * (unsigned)a.nu;
+    }
+    const float *sino_z0 = a.sino + (size_t)z0 * zstride;
+
+    auto window = [&](int a0, int buf) {  // detector window of the brick for the 8 angles of a batch
+        if (tid < BB_AB) {
+            // the coordinate is monotone in x and in y, so the four corners bound it
+            const tomo_angle_t t = a.tab[min(a0 + tid, a.na - 1)];
+            const float off = half_u - t.cor;
+            const float x0 = (float)tx0 - half_n, x1 = (float)(tx0 + BB_TX - 1) - half_n;
+            const float y0 = (float)ty0 - half_n, y1 = (float)(ty0 + BB_TY - 1) - half_n;
+            const float f00 = fmaf(x0, t.cs, fmaf(y0, t.sn, off)), f10 = fmaf(x1, t.cs, fmaf(y0, t.sn, off));
+            const float f01 = fmaf(x0, t.cs, fmaf(y1, t.sn, off)), f11 = fmaf(x1, t.cs, fmaf(y1, t.sn, off));
+            // clamp so that the int conversion and the offsets below stay in range whatever the geometry
+            const float lo = fminf(fminf(f00, f10), fminf(f01, f11));
+            umin_s[buf][tid] = (int)fminf(fmaxf(floorf(lo), -1.0e6f), 1.0e6f);
+        }
+    };
+
+    float4 pre[BB_ITEMS];
+    auto prefetch = [&](int a0, int buf) {  // batch a0 -> registers (zero outside the detector)
+        const float *base = sino_z0 + (size_t)a0 * a.nu;
+        const int amax = a.na - 1 - a0;  // angle slots beyond the subset re-read the last angle (never sampled)
+#pragma unroll
+        for (int m = 0; m < BB_ITEMS; ++m) {
+            const int u = umin_s[buf][it_aa[m]] + it_j[m];
+            const unsigned mk = (u >= 0 && u < a.nu) ? 0xffffffffu : 0u;
+            unsigned off = it_off[m] + (unsigned)min(max(u, 0), a.nu - 1);
+            if (it_aa[m] > amax) off -= (unsigned)(it_aa[m] - amax) * (unsigned)a.nu;
+            float4 v;
+            if (!ragged) {
+                v.x = base[off];
+                v.y = base[off + zstride];
+                v.z = base[off + 2 * zstride];
+                v.w = base[off + 3 * zstride];
+            } else {  // slices past the end of the volume are fed by the last valid one; their accumulators are not stored
+                const int zrel = min(4 * (((tid + 256 * m) / BB_PITCH) % BB_ZQ), zlim);
+                v.x = base[off];
+                v.y = base[off + (unsigned)(min(zrel + 1, zlim) - zrel) * zstride];
+                v.z = base[off + (unsigned)(min(zrel + 2, zlim) - zrel) * zstride];
+                v.w = base[off + (unsigned)(min(zrel + 3, zlim) - zrel) * zstride];
+            }
+            v.x = __uint_as_float(__float_as_uint(v.x) & mk);
+            v.y = __uint_as_float(__float_as_uint(v.y) & mk);
+            v.z = __uint_as_float(__float_as_uint(v.z) & mk);
+            v.w = __uint_as_float(__float_as_uint(v.w) & mk);
+            pre[m] = v;
+        }
+    };
+
+    window(0, 0);
+    __syncthreads();
+    prefetch(0, 0);
+    int buf = 0;
+    for (int a0 = 0; a0 < a.na; a0 += BB_AB, buf = (buf == 2 ? 0 : buf + 1)) {
+        const int nb = min(BB_AB, a.na - a0);
+        const bool more = a0 + BB_AB < a.na;
+        const int nbuf = (buf == 2 ? 0 : buf + 1);
+        if (more) window(a0 + BB_AB, nbuf);
+        // double-buffered tile: waves still sampling batch b-1 read the other buffer, so one barrier per batch is enough
+        float4 *tile = tile2[(a0 / BB_AB) & 1];
+#pragma unroll
+        for (int m = 0; m < BB_ITEMS; ++m) tile[tid + 256 * m] = pre[m];
+        __syncthreads();  // tile b and the window of batch b+1 visible; everyone is past the sampling of batch b-1
+        if (more) prefetch(a0 + BB_AB, nbuf);  // in flight while this batch is sampled
+        auto sample = [&](int aa) {
+            const tomo_angle_t t = a.tab[a0 + aa];
+            const float off = half_u - t.cor;
+            // the window origin is wave-uniform: fold it into a scalar byte offset so that a tap address is one v_lshl_add
+            int ab = __builtin_amdgcn_readfirstlane((aa * (BB_ZQ * BB_PITCH) - umin_s[buf][aa]) * 16);
+            asm("" : "+s"(ab));  // opaque: otherwise the *16 is factored back out (a second VALU op per tap)
+            const char *tb = reinterpret_cast<const char *>(tile);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float f = fmaf(xw, t.cs, fmaf(r ? yw1 : yw0, t.sn, off));
+                const float fl = floorf(f);
+                const float w = lerp_w<LERP8>(f, fl), omw = 1.0f - w;
+                const int idx = (int)fl;
+                const v2f w2 = v2f{w, w}, omw2 = v2f{omw, omw};
+#pragma unroll
+                for (int zq = 0; zq < BB_ZQ; ++zq) {
+                    const v4f *tap = reinterpret_cast<const v4f *>(tb + ((idx << 4) + ab)) + zq * BB_PITCH;
+                    const v4f s0 = tap[0], s1 = tap[1];
+                    v2f &c0 = acc[r][zq * 2], &c1 = acc[r][zq * 2 + 1];
+                    c0 = __builtin_elementwise_fma(omw2, s0.lo, c0); c0 = __builtin_elementwise_fma(w2, s1.lo, c0);
+                    c1 = __builtin_elementwise_fma(omw2, s0.hi, c1); c1 = __builtin_elementwise_fma(w2, s1.hi, c1);
+                }
+            }
+        };
+        if (nb == BB_AB) {  // unrolled: the 8 angle records become one block of scalar loads ahead of the sampling
+#pragma unroll
+            for (int aa = 0; aa < BB_AB; ++aa) sample(aa);
+        } else {
+            for (int aa = 0; aa < nb; ++aa) sample(aa);
+        }
+    }
+    if (ix < a.n) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int iy = iy0 + 4 * r;
+            if (iy < a.n) {
+#pragma unroll
+                for (int j = 0; j < 4 * BB_ZQ; ++j)
+                    if (z0 + j < a.nz) bp_epilogue<EPI>(a, ((size_t)(z0 + j) * a.n + iy) * a.n + ix, acc[r][j >> 1][j & 1]);
+            }
+        }
+    }
+}

@@ -10,8 +10,7 @@
 // chunk.  Each (pixel, angle, slice) accumulator lives in a register and is summed in march order, so the result is
 // bit-identical to the sequential oracle.
 constexpr int FP_A = 8;               // angles per workgroup
-constexpr int FP_M = 8;               // float4 staging items per thread and chunk (register prefetch depth)
-constexpr int FP_MAX_WPITCH = 1024;   // 4 passes of 256 columns
+constexpr int FP_MAX_WPITCH = 1280;   // 5 passes of 256 columns
 
 struct FpTiledArgs {
     const float *src;        // volume with the interpolation axis contiguous ([nz][n][n])
@@ -26,16 +25,19 @@ struct FpTiledArgs {
     int nut, ngroups, nzb;   // detector tiles, angle groups, slice quads
 };
 
-// PASSES = ceil(wpitch / 256) column passes per staged row; KC = FP_M / PASSES rows per chunk (compile-time so that the
+// PASSES = ceil(wpitch / 256) column passes per staged row; KC = M / PASSES rows per chunk (compile-time so that the
 // staging index arithmetic is free of integer divisions).
-template <bool LERP8, bool RESID, int PASSES>
+// M = float4 staging items per thread and chunk (register prefetch depth).  DB: double-buffered tile, one barrier per
+// chunk (narrow windows); !DB: one tile, two barriers per chunk -- half the LDS, so wide windows (the 12-strided
+// angles of an ordered subset) still get several rows per chunk and 3 workgroups per CU.
+template <bool LERP8, bool RESID, int PASSES, int M, bool DB>
 __global__ __launch_bounds__(256) void fp_tiled_kernel(FpTiledArgs a)
 {
-    constexpr int KC = FP_M / PASSES;
+    constexpr int KC = M / PASSES;
     extern __shared__ __attribute__((aligned(16))) unsigned char fp_smem[];
     const int tile_items = KC * a.wpitch;
     float4 *tile0 = reinterpret_cast<float4 *>(fp_smem);
-    float4 *tile1 = tile0 + tile_items;
+    float4 *tile1 = DB ? tile0 + tile_items : tile0;
     int *win_lo = reinterpret_cast<int *>(tile1 + tile_items);  // [n]
     int *win_wid = win_lo + a.n;                                // [n]
 
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void fp_tiled_kernel(FpTiledArgs a)
     const int ng = min(FP_A, a.n_class - g * FP_A);   // angles in this group (uniform)
     const int *ord = a.order + g * FP_A;
 
-    const float half_n = 0.5f * (float)n - 0.5f, half_u = 0.5f * (float)a.nu - 0.5f;
+    const float half_n = 0.5f * (float)n - 0.5f, half_u = 0.5f * (float)a.nu - 0.5f, nf = (float)n;
     float offs[FP_A], slope[FP_A], acc[FP_A][4];
 #pragma unroll
     for (int i = 0; i < FP_A; ++i) {
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void fp_tiled_kernel(FpTiledArgs a)
     const float *p3 = a.src + (size_t)min(z0 + 3, a.nz - 1) * zstride;
     const unsigned k1 = z0 + 1 < a.nz ? 0xffffffffu : 0u, k2 = z0 + 2 < a.nz ? 0xffffffffu : 0u, k3 = z0 + 3 < a.nz ? 0xffffffffu : 0u;
 
-    float4 pre[FP_M];
+    float4 pre[M];
     // branch-free gather of the chunk starting at row k0 into registers: pre[r * PASSES + p] <- (row k0+r, column tid+256p).
     // Invalid items (outside the window / volume / march) load a clamped address and are zeroed with a bit mask.
     auto prefetch = [&](int k0) {
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(256) void fp_tiled_kernel(FpTiledArgs a)
     prefetch(0);
     for (int c = 0; c < nchunks; ++c) {
         float4 *tile = (c & 1) ? tile1 : tile0;
+        if (!DB) __syncthreads();  // every wave is past the sampling of chunk c-1 (same buffer)
 #pragma unroll
         for (int r = 0; r < KC; ++r)
 #pragma unroll
@@ -139,16 +142,19 @@ __global__ __launch_bounds__(256) void fp_tiled_kernel(FpTiledArgs a)
             // so they add exactly nothing and no tail branch is needed
             const int kr = min(k0 + r, n - 1);
             const float kw = (float)kr - half_n;
-            const int lo = win_lo[kr];
-            const float4 *trow = tile + r * a.wpitch;
+            // the row/window origin is wave-uniform: keep it in a scalar so that a tap address is one v_lshl_add
+            int rb = __builtin_amdgcn_readfirstlane((r * a.wpitch - win_lo[kr]) * 16);
+            asm("" : "+s"(rb));  // opaque: otherwise the *16 is factored back out and costs a second VALU op per tap
+            const char *trow = reinterpret_cast<const char *>(tile);
 #pragma unroll
             for (int i = 0; i < FP_A; ++i) {  // slots >= ng repeat angle 0 (never stored)
                 const float f = fmaf(kw, slope[i], offs[i]);
                 const float fl = floorf(f);
                 const float w = lerp_w<LERP8>(f, fl), omw = 1.0f - w;
-                // rays outside [-2, n] sample the zero columns; clamp in float so the int conversion is safe
-                const int idx = (int)fminf(fmaxf(fl, -2.0f), (float)n) - lo;
-                const float4 s0 = trow[idx], s1 = trow[idx + 1];
+                // rays outside [-2, n] sample the zero columns: one v_med3_f32, then one v_lshl_add for the address
+                const int idx = (int)__builtin_amdgcn_fmed3f(fl, -2.0f, nf);
+                const float4 *tap = reinterpret_cast<const float4 *>(trow + ((idx << 4) + rb));
+                const float4 s0 = tap[0], s1 = tap[1];
                 acc[i][0] = fmaf(omw, s0.x, acc[i][0]); acc[i][0] = fmaf(w, s1.x, acc[i][0]);
                 acc[i][1] = fmaf(omw, s0.y, acc[i][1]); acc[i][1] = fmaf(w, s1.y, acc[i][1]);
                 acc[i][2] = fmaf(omw, s0.z, acc[i][2]); acc[i][2] = fmaf(w, s1.z, acc[i][2]);
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(BT) void fp_tiled_sync_kernel(FpTiledArgs a, int kc
     const int z0 = zb * 4, u0 = ut * BT, tid = (int)threadIdx.x, iu = u0 + tid, n = a.n;
     const int ng = min(A, a.n_class - g * A);
     const int *ord = a.order + g * A;
-    const float half_n = 0.5f * (float)n - 0.5f, half_u = 0.5f * (float)a.nu - 0.5f;
+    const float half_n = 0.5f * (float)n - 0.5f, half_u = 0.5f * (float)a.nu - 0.5f, nf = (float)n;
     float offs[A], slope[A], acc[A][4];
 #pragma unroll
     for (int i = 0; i < A; ++i) {
@@ -294,15 +300,17 @@ __global__ __launch_bounds__(BT) void fp_tiled_sync_kernel(FpTiledArgs a, int kc
         __syncthreads();
         for (int r = 0; r < rows; ++r) {
             const float kw = (float)(k0 + r) - half_n;
-            const int lo = xlo_s[r];
-            const float4 *trow = tile + (size_t)r * a.wpitch;
+            int rb = __builtin_amdgcn_readfirstlane((r * a.wpitch - xlo_s[r]) * 16);  // see fp_tiled_kernel
+            asm("" : "+s"(rb));
+            const char *trow = reinterpret_cast<const char *>(tile);
 #pragma unroll
             for (int i = 0; i < A; ++i) {
                 const float f = fmaf(kw, slope[i], offs[i]);
                 const float fl = floorf(f);
                 const float w = lerp_w<LERP8>(f, fl), omw = 1.0f - w;
-                const int idx = (int)fminf(fmaxf(fl, -2.0f), (float)n) - lo;
-                const float4 s0 = trow[idx], s1 = trow[idx + 1];
+                const int idx = (int)__builtin_amdgcn_fmed3f(fl, -2.0f, nf);
+                const float4 *tap = reinterpret_cast<const float4 *>(trow + ((idx << 4) + rb));
+                const float4 s0 = tap[0], s1 = tap[1];
                 acc[i][0] = fmaf(omw, s0.x, acc[i][0]); acc[i][0] = fmaf(w, s1.x, acc[i][0]);
                 acc[i][1] = fmaf(omw, s0.y, acc[i][1]); acc[i][1] = fmaf(w, s1.y, acc[i][1]);
                 acc[i][2] = fmaf(omw, s0.z, acc[i][2]); acc[i][2] = fmaf(w, s1.z, acc[i][2]);

@@ -215,14 +215,26 @@ __global__ __launch_bounds__(256) void bp_tiled_kernel(BpArgs a)
     }
 }
 
+#include "bp_brick.inl"
+
 template <int EPI>
 int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
 {
     tomo_prof_scope prof(PROF_BP, st, 1);
-    if (g_variant_bp == 1) {
+    // the brick kernel addresses a 16-slice sinogram slab with 32-bit element offsets
+    const bool brick_ok = (long)a.na * a.nu < (1L << 27);
+    if (g_variant_bp == 1 || (g_variant_bp == 0 && !brick_ok)) {
         dim3 grid(ceil_div(a.n, 64), ceil_div(a.n, 4), ceil_div(a.nz, 4));
         if (lerp8) bp_direct_kernel<EPI, true><<<grid, 256, 0, st>>>(a);
         else bp_direct_kernel<EPI, false><<<grid, 256, 0, st>>>(a);
+    } else if (g_variant_bp == 0) {
+        a.ntx = ceil_div(a.n, BB_TX);
+        a.nty = ceil_div(a.n, BB_TY);
+        a.nzb = ceil_div(a.nz, 4 * BB_ZQ);
+        const long blocks = 8L * ceil_div(a.nzb, 8) * a.ntx * a.nty;
+        if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one BP launch");
+        if (lerp8) bp_brick_kernel<EPI, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+        else bp_brick_kernel<EPI, false><<<(unsigned)blocks, 256, 0, st>>>(a);
     } else {
         a.ntx = ceil_div(a.n, BP_TX);
         a.nty = ceil_div(a.n, BP_TY);
@@ -383,9 +395,12 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
                 t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
                 t.wpitch = s.wbound[c];
-                const int passes = ceil_div(t.wpitch, 256);           // 1..4
-                const int kc = FP_M / (passes == 3 ? 4 : passes);      // template instances: 1, 2, 4 passes
-                const size_t smem = (size_t)2 * kc * t.wpitch * 16 + (size_t)a.n * 8;
+                const int passes = ceil_div(t.wpitch, 256);           // 1..5 in the pipelined kernel
+                // (items per thread, double buffer) per pass count -- keep in step with FP_TILED_LAUNCH below
+                const int fp_m = passes <= 2 ? 8 : (passes == 5 ? 10 : 12);
+                const bool fp_db = passes <= 2;
+                const int kc = fp_m / std::max(passes, 1);
+                const size_t smem = (size_t)(fp_db ? 2 : 1) * kc * t.wpitch * 16 + (size_t)a.n * 8;
                 t.nut = ceil_div(a.nu, 256);
                 t.ngroups = ceil_div(nc, FP_A);
                 t.nzb = ceil_div(a.nz, 4);
@@ -395,7 +410,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 // windows (ordered subsets spread the angles of a group) run the synchronous form, whose small LDS
                 // footprint lets many workgroups per CU hide the staging latency.  Measured on MI355X:
                 // 512^3 x 360 angles 8.4 ms (pipelined) vs 10.0 (sync); 1024^3 x 75 angles 22 ms (sync).
-                static const int pipe_max = getenv("TOMO_FP_PIPE_MAX") ? atoi(getenv("TOMO_FP_PIPE_MAX")) : 512;
+                static const int pipe_max = getenv("TOMO_FP_PIPE_MAX") ? atoi(getenv("TOMO_FP_PIPE_MAX")) : FP_MAX_WPITCH;
                 if (g_variant_fp == 2 || t.wpitch > std::min(pipe_max, FP_MAX_WPITCH)) {
                     static const int lds_budget = getenv("TOMO_FP_LDS") ? atoi(getenv("TOMO_FP_LDS")) : 40000;
                     // wide windows: a wider detector tile (more threads per workgroup) shares the spread-induced part
@@ -438,9 +453,11 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 }
 #define FP_TILED_LAUNCH(L8, RES)                                                                          \
     do {                                                                                                  \
-        if (passes == 1) fp_tiled_kernel<L8, RES, 1><<<(unsigned)blocks, 256, smem, st>>>(t);             \
-        else if (passes == 2) fp_tiled_kernel<L8, RES, 2><<<(unsigned)blocks, 256, smem, st>>>(t);        \
-        else fp_tiled_kernel<L8, RES, 4><<<(unsigned)blocks, 256, smem, st>>>(t);                         \
+        if (passes == 1) fp_tiled_kernel<L8, RES, 1, 8, true><<<(unsigned)blocks, 256, smem, st>>>(t);        \
+        else if (passes == 2) fp_tiled_kernel<L8, RES, 2, 8, true><<<(unsigned)blocks, 256, smem, st>>>(t);   \
+        else if (passes == 3) fp_tiled_kernel<L8, RES, 3, 12, false><<<(unsigned)blocks, 256, smem, st>>>(t); \
+        else if (passes == 4) fp_tiled_kernel<L8, RES, 4, 12, false><<<(unsigned)blocks, 256, smem, st>>>(t); \
+        else fp_tiled_kernel<L8, RES, 5, 10, false><<<(unsigned)blocks, 256, smem, st>>>(t);                  \
     } while (0)
                 if (b) { if (l8) FP_TILED_LAUNCH(true, true); else FP_TILED_LAUNCH(false, true); }
                 else   { if (l8) FP_TILED_LAUNCH(true, false); else FP_TILED_LAUNCH(false, false); }

@@ -290,7 +290,7 @@ int pd_launch(const PdArgs &a0, int variant, hipStream_t st)
         dim3 grid(ceil_div(a.dx, 256), a.dy, nout);
         pd_pervoxel_kernel<T, ND, NONNEG, ANISO><<<grid, 256, 0, st>>>(a);
     } else if (variant == 0 || (variant >= 3 && variant <= 5)) {
-        // measured on MI355X, 1024^3 f32 duals (profiles/r1_pdtv_variants.txt): 4x2 waves x 8 rows, lockstep = 8.6 ms;
+        // measured on MI355X, 1024^3 f32 duals (profiles/r1_pdtv_pmc.txt): 4x2 waves x 8 rows, lockstep = 8.6 ms;
         // 4x4 waves x 4 rows = 9.2 ms; 4x1 x 8 rows = 8.7 ms; unsynchronised waves (1x4, 4 rows) = 12.3-14 ms
         int rc = (variant == 0)   ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 8, true, 4, 2>(a, st)
                  : (variant == 3) ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 4, true, 4, 4>(a, st)

@@ -37,7 +37,7 @@ vol = torch.rand((NZ, N, N), device="cuda")
 sino = torch.rand((NZ, NA, N), device="cuda")
 out_v = torch.empty_like(vol)
 out_s = torch.empty_like(sino)
-for variant in (0, 1):
+for variant in (0, 2, 1):
     ops.set_variant("bp", variant)
     ms = timeit(lambda: H.backward(sino, None, out=out_v))
     print(f"BP  variant {variant}: {ms:8.3f} ms  {4*(S+V)/ms/1e6:8.1f} GB/s alg  {V*NA/ms/1e6:8.1f} GUPS")
