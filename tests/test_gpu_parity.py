@@ -48,6 +48,8 @@ GEOMS = [
     (18, 70, 64, 31, -2.5, 4),      # several z-batches, detector narrower than the grid, OS with a trimmed subset
     (1, 130, 130, 50, 0.0, 7),      # single slice (2D case), >2 x-tiles
     (33, 24, 24, 9, "vec", 2),      # per-angle CoR vector, nz not a multiple of 16
+    (6, 800, 800, 25, 0.0, 1),      # wide detector: the 1024-thread whole-row FP kernel, 25 BP bricks per row
+    (5, 780, 900, 18, 0.7, 3),      # same with detector != grid, CoR offset, subsets of 6 angles (tail batches)
 ]
 
 

@@ -25,13 +25,18 @@ struct FpTiledArgs {
     int nut, ngroups, nzb;   // detector tiles, angle groups, slice quads
 };
 
-// PASSES = ceil(wpitch / 256) column passes per staged row; KC = M / PASSES rows per chunk (compile-time so that the
+// BT = workgroup size = detector pixels per workgroup.  256: several workgroups per CU.  1024: the workgroup spans the
+// whole detector row of a 1024-wide problem, so every volume row is staged once per angle group instead of once per
+// (angle group, detector tile) with overlapping windows -- the 12-strided angles of an ordered subset spread a 256-pixel
+// tile's window to ~480 columns, i.e. 4 x 480 instead of 1030 per row; measured L2->fabric traffic 55 GB per call with
+// 256-pixel tiles (profiles/r1_bp_fp_pmc.txt) because the 12-20 workgroups sharing a slice quad drift apart.
+// PASSES = ceil(wpitch / BT) column passes per staged row; KC = M / PASSES rows per chunk (compile-time so that the
 // staging index arithmetic is free of integer divisions).
 // M = float4 staging items per thread and chunk (register prefetch depth).  DB: double-buffered tile, one barrier per
 // chunk (narrow windows); !DB: one tile, two barriers per chunk -- half the LDS, so wide windows (the 12-strided
 // angles of an ordered subset) still get several rows per chunk and 3 workgroups per CU.
-template <bool LERP8, bool RESID, int PASSES, int M, bool DB>
-__global__ __launch_bounds__(256) void fp_tiled_kernel(FpTiledArgs a)
+template <bool LERP8, bool RESID, int PASSES, int M, bool DB, int BT>
+__global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
 {
     constexpr int KC = M / PASSES;
     extern __shared__ __attribute__((aligned(16))) unsigned char fp_smem[];
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(256) void fp_tiled_kernel(FpTiledArgs a)
     const int rest = q % per_zb;
     const int ut = rest % a.nut, g = rest / a.nut;
     const int z0 = zb * 4;
-    const int u0 = ut * 256;
+    const int u0 = ut * BT;
     const int tid = (int)threadIdx.x;
     const int iu = u0 + tid;
     const int n = a.n;
@@ -70,13 +75,13 @@ __global__ __launch_bounds__(256) void fp_tiled_kernel(FpTiledArgs a)
 
     // ---- window of every march row (the sampling coordinate is monotone in the detector index, so the two ends of
     //      the detector tile bound it); two zero columns on either side (-2,-1 / n,n+1) absorb rays that miss the volume
-    for (int k = tid; k < n; k += 256) {
+    for (int k = tid; k < n; k += BT) {
         const float kw = (float)k - half_n;
         float fmin = 3.0e38f, fmax = -3.0e38f;
         for (int i = 0; i < ng; ++i) {
             const tomo_angle_t t = a.tab[ord[i]];
             const float o0 = fmaf(((float)u0 - half_u) + t.cor, t.inv, half_n);
-            const float o1 = fmaf(((float)(u0 + 255) - half_u) + t.cor, t.inv, half_n);
+            const float o1 = fmaf(((float)(u0 + BT - 1) - half_u) + t.cor, t.inv, half_n);
             const float f0 = fmaf(kw, t.slope, o0), f1 = fmaf(kw, t.slope, o1);
             fmin = fminf(fmin, fminf(f0, f1));
             fmax = fmaxf(fmax, fmaxf(f0, f1));
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256) void fp_tiled_kernel(FpTiledArgs a)
     const unsigned k1 = z0 + 1 < a.nz ? 0xffffffffu : 0u, k2 = z0 + 2 < a.nz ? 0xffffffffu : 0u, k3 = z0 + 3 < a.nz ? 0xffffffffu : 0u;
 
     float4 pre[M];
-    // branch-free gather of the chunk starting at row k0 into registers: pre[r * PASSES + p] <- (row k0+r, column tid+256p).
+    // branch-free gather of the chunk starting at row k0 into registers: pre[r * PASSES + p] <- (row k0+r, column tid + BT p).
     // Invalid items (outside the window / volume / march) load a clamped address and are zeroed with a bit mask.
     auto prefetch = [&](int k0) {
 #pragma unroll
@@ -107,15 +112,19 @@ __global__ __launch_bounds__(256) void fp_tiled_kernel(FpTiledArgs a)
             const unsigned rowoff = (unsigned)k * (unsigned)n;
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
-                const int j = tid + 256 * p;
+                const int j = tid + BT * p;
                 const int x = lo + j;
                 const unsigned mk = (j < wid && x >= 0 && x < n) ? 0xffffffffu : 0u;
                 const unsigned off = rowoff + (unsigned)min(max(x, 0), n - 1);
-                float4 v;
-                v.x = __uint_as_float(__float_as_uint(p0[off]) & mk);
-                v.y = __uint_as_float(__float_as_uint(p1[off]) & (mk & k1));
-                v.z = __uint_as_float(__float_as_uint(p2[off]) & (mk & k2));
-                v.w = __uint_as_float(__float_as_uint(p3[off]) & (mk & k3));
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                // a wave whose 64 columns all lie beyond the window skips the pass (wave-uniform: scalar branch); with
+                // BT = 1024 the second pass of a 1030-column row keeps one wave of sixteen busy
+                if (p == 0 || __builtin_amdgcn_readfirstlane(j - (tid & 63)) < __builtin_amdgcn_readfirstlane(wid)) {
+                    v.x = __uint_as_float(__float_as_uint(p0[off]) & mk);
+                    v.y = __uint_as_float(__float_as_uint(p1[off]) & (mk & k1));
+                    v.z = __uint_as_float(__float_as_uint(p2[off]) & (mk & k2));
+                    v.w = __uint_as_float(__float_as_uint(p3[off]) & (mk & k3));
+                }
                 pre[r * PASSES + p] = v;
             }
         }
@@ -130,8 +139,9 @@ __global__ __launch_bounds__(256) void fp_tiled_kernel(FpTiledArgs a)
         for (int r = 0; r < KC; ++r)
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
-                const int j = tid + 256 * p;
-                if (j < a.wpitch) tile[r * a.wpitch + j] = pre[r * PASSES + p];
+                const int j = tid + BT * p;
+                if (p == 0 || __builtin_amdgcn_readfirstlane(j - (tid & 63)) < a.wpitch)
+                    if (j < a.wpitch) tile[r * a.wpitch + j] = pre[r * PASSES + p];
             }
         __syncthreads();  // chunk c staged; every wave is past the sampling of chunk c-1 (other buffer)
         const int k0 = c * KC;

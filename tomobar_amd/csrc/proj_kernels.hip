@@ -406,6 +406,45 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 t.nzb = ceil_div(a.nz, 4);
                 const long blocks = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
                 TOMO_REQUIRE(blocks <= 0x7fffffffL, "problem too large for one FP launch");
+                // ---- wide form: one 1024-thread workgroup per detector row (see fp_tiled.inl).  Chosen when the 256-pixel
+                // tiles of a row would stage >= 1.25x what the whole row needs (ordered subsets), and it fits in LDS.
+                {
+                    static const int wide_env = getenv("TOMO_FP_WIDE") ? atoi(getenv("TOMO_FP_WIDE")) : -1;  // -1 auto
+                    if (wide_env != 0 && g_variant_fp == 0 && a.nu >= 768) {
+                        if (s.wbound_wide[c] < 0)
+                            s.wbound_wide[c] = fp_window_bound(ctx->host_table.data() + s.table_offset,
+                                                               ctx->host_fp_order.data() + order_off, nc, ctx->n, ctx->nu, 1024);
+                        const int wp = s.wbound_wide[c];
+                        const int nut_w = ceil_div(a.nu, 1024);
+                        const bool pays = wide_env == 1 || (double)t.nut * t.wpitch >= 1.25 * (double)nut_w * wp;
+                        const int passes_w = ceil_div(wp, 1024);
+                        int kc_w = 4;
+                        size_t smem_w = (size_t)2 * kc_w * wp * 16 + (size_t)a.n * 8;
+                        if (smem_w > 160 * 1024) { kc_w = 2; smem_w = (size_t)2 * kc_w * wp * 16 + (size_t)a.n * 8; }
+                        if (pays && passes_w <= 2 && smem_w <= 160 * 1024) {
+                            t.wpitch = wp;
+                            t.nut = nut_w;
+                            const long blocks_w = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
+#define FP_WIDE_LAUNCH(L8, RES)                                                                                        \
+    do {                                                                                                               \
+        auto launch = [&](auto kern) {                                                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)smem_w);                                                                    \
+            kern<<<(unsigned)blocks_w, 1024, smem_w, st>>>(t);                                                         \
+        };                                                                                                             \
+        if (passes_w == 1) launch(fp_tiled_kernel<L8, RES, 1, 4, true, 1024>);                                         \
+        else if (kc_w == 4) launch(fp_tiled_kernel<L8, RES, 2, 8, true, 1024>);                                        \
+        else launch(fp_tiled_kernel<L8, RES, 2, 4, true, 1024>);                                                       \
+    } while (0)
+                            if (b) { if (l8) FP_WIDE_LAUNCH(true, true); else FP_WIDE_LAUNCH(false, true); }
+                            else   { if (l8) FP_WIDE_LAUNCH(true, false); else FP_WIDE_LAUNCH(false, false); }
+#undef FP_WIDE_LAUNCH
+                            TOMO_LAUNCH_CHECK();
+                            order_off += nc;
+                            continue;
+                        }
+                    }
+                }
                 // Narrow windows (dense angle sets: <= 2 column passes) run the register-prefetch pipeline; wide
                 // windows (ordered subsets spread the angles of a group) run the synchronous form, whose small LDS
                 // footprint lets many workgroups per CU hide the staging latency.  Measured on MI355X:
@@ -453,11 +492,11 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 }
 #define FP_TILED_LAUNCH(L8, RES)                                                                          \
     do {                                                                                                  \
-        if (passes == 1) fp_tiled_kernel<L8, RES, 1, 8, true><<<(unsigned)blocks, 256, smem, st>>>(t);        \
-        else if (passes == 2) fp_tiled_kernel<L8, RES, 2, 8, true><<<(unsigned)blocks, 256, smem, st>>>(t);   \
-        else if (passes == 3) fp_tiled_kernel<L8, RES, 3, 12, false><<<(unsigned)blocks, 256, smem, st>>>(t); \
-        else if (passes == 4) fp_tiled_kernel<L8, RES, 4, 12, false><<<(unsigned)blocks, 256, smem, st>>>(t); \
-        else fp_tiled_kernel<L8, RES, 5, 10, false><<<(unsigned)blocks, 256, smem, st>>>(t);                  \
+        if (passes == 1) fp_tiled_kernel<L8, RES, 1, 8, true, 256><<<(unsigned)blocks, 256, smem, st>>>(t);        \
+        else if (passes == 2) fp_tiled_kernel<L8, RES, 2, 8, true, 256><<<(unsigned)blocks, 256, smem, st>>>(t);   \
+        else if (passes == 3) fp_tiled_kernel<L8, RES, 3, 12, false, 256><<<(unsigned)blocks, 256, smem, st>>>(t); \
+        else if (passes == 4) fp_tiled_kernel<L8, RES, 4, 12, false, 256><<<(unsigned)blocks, 256, smem, st>>>(t); \
+        else fp_tiled_kernel<L8, RES, 5, 10, false, 256><<<(unsigned)blocks, 256, smem, st>>>(t);                  \
     } while (0)
                 if (b) { if (l8) FP_TILED_LAUNCH(true, true); else FP_TILED_LAUNCH(false, true); }
                 else   { if (l8) FP_TILED_LAUNCH(true, false); else FP_TILED_LAUNCH(false, false); }

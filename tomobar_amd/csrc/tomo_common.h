@@ -44,6 +44,7 @@ struct tomo_subset {
     // (e.g. theta near 0 and near pi) sample opposite ends of a volume row and must not share a staged window
     int n_class[4] = {0, 0, 0, 0};
     int wbound[4] = {-1, -1, -1, -1};
+    int wbound_wide[4] = {-1, -1, -1, -1};  // same for 1024-pixel detector tiles
 };
 
 struct tomo_ctx {
