@@ -201,6 +201,13 @@ int tomo_pdtv_pair_slab(int device, const float *in_dev, const float *u_in_dev, 
                         const void *p_in_dev[3], void *p_out_dev[3], int dx, int dy, int nz_local,
                         int lo_planes, int hi_planes, float sigma, float tau, float lt, float theta,
                         int methodTV, int nonneg, int half, void *stream);
+/* Same, restricted to the local output planes [z_begin, z_end) (0 <= z_begin <= z_end <= nz_local).  Lets a rank
+ * compute the planes its neighbours wait for first, start the halo exchange, and compute the interior while the
+ * planes travel (tomobar_amd/slab.py).  tomo_pdtv_pair_slab == the range [0, nz_local). */
+int tomo_pdtv_pair_slab_range(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
+                              const void *p_in_dev[3], void *p_out_dev[3], int dx, int dy, int nz_local,
+                              int lo_planes, int hi_planes, int z_begin, int z_end, float sigma, float tau,
+                              float lt, float theta, int methodTV, int nonneg, int half, void *stream);
 int tomo_roftv_iter_slab(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
                          int dx, int dy, int nz_local, int lo_planes, int hi_planes,
                          float lambda, float tau, int half, void *stream);

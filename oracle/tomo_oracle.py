@@ -235,7 +235,8 @@ def pd_step_slab(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, has_lo, has_hi, sig
         p_out[c][lo:lo + nzl] = torch.from_numpy(pout[c][lo:lo + nzl]).to(p_out[c].dtype)
 
 
-def pd_pair_slab(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, lo, hi, sigma, tau, lt, theta, methodTV, nonneg, half):
+def pd_pair_slab(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, lo, hi, sigma, tau, lt, theta, methodTV, nonneg, half,
+                 zr=None):
     """Two PD_TV iterations on a slab with two-plane ghosts (signature of tomobar_amd.slab._hip_pd_pair), as two
     applications of orc_pdtv_step: the first one also produces the planes next to the slab that the second one reads."""
     import torch
@@ -261,9 +262,10 @@ def pd_pair_slab(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, lo, hi, sigma, tau,
     L.orc_pdtv_step(_fptr(i_np), _fptr(u1), _fptr(u2), _fptr(p1[0]), _fptr(p1[1]), _fptr(p1[2]), _fptr(p2[0]),
                     _fptr(p2[1]), _fptr(p2[2]), dx, dy, planes, lo, lo + nzl, first_edge, last_edge, sigma, tau, lt, theta,
                     int(bool(methodTV)), int(bool(nonneg)), int(bool(half)))
-    u_out[lo:lo + nzl] = torch.from_numpy(u2[lo:lo + nzl])
+    z0, z1 = zr if zr is not None else (0, nzl)  # only these local planes are written (tomo_pdtv_pair_slab_range)
+    u_out[lo + z0:lo + z1] = torch.from_numpy(u2[lo + z0:lo + z1])
     for c in range(3):
-        p_out[c][lo:lo + nzl] = torch.from_numpy(p2[c][lo:lo + nzl]).to(p_out[c].dtype)
+        p_out[c][lo + z0:lo + z1] = torch.from_numpy(p2[c][lo + z0:lo + z1]).to(p_out[c].dtype)
 
 
 def rof_step_slab(inp, u_in, u_out, dx, dy, nzl, lo, hi, lam, tau, half):

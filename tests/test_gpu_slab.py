@@ -21,8 +21,10 @@ def _copy_halos(states, b):
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("half", [False, True])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, "ranges"])
 def test_pdtv_slabs_equal_whole_volume(world, half, variant):
+    ranges = variant == "ranges"  # the overlapped schedule of pd_tv_slab: edge planes first, then the interior
+    variant = 0 if ranges else variant
     from tomobar_amd import ops
     from tomobar_amd.regularisersCuPy import PD_TV_cupy
     from tomobar_amd.slab import PdSlab, _hip_pd_pair, _hip_pd_step, slab_bounds
@@ -49,6 +51,18 @@ def test_pdtv_slabs_equal_whole_volume(world, half, variant):
                     dst.copy_(src)
             it = 0
             while it < iters:
+                if ranges and iters - it >= 2:
+                    args = (sigma, tau, lt, np.float32(1.0), 0, 1)
+                    for s in states:
+                        for z0, z1 in s.boundary_ranges()[0]:
+                            s.pair_range(*args, z0, z1)
+                    _copy_halos(states, states[0].cur ^ 1)  # "in flight" while the interiors are computed
+                    for s in states:
+                        b0, b1 = s.boundary_ranges()[1]
+                        s.pair_range(*args, b0, b1)
+                        s.flip()
+                    it += 2
+                    continue
                 for s in states:
                     if iters - it >= 2:
                         s.pair(sigma, tau, lt, np.float32(1.0), 0, 1)

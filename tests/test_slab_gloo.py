@@ -55,6 +55,10 @@ def _worker(rank, world, port, case):
 CASES = [
     dict(kind="pd", shape=(9, 7, 11), iters=6, mtv=0, nn=0, half=False),
     dict(kind="pd", shape=(8, 6, 70), iters=5, mtv=1, nn=1, half=True),
+    # slabs long enough for the overlapped schedule (edge planes, exchange in flight, interior); with 3 ranks the
+    # middle slab is too short and falls back to the plain schedule while its neighbours overlap
+    dict(kind="pd", shape=(19, 6, 13), iters=7, mtv=0, nn=1, half=False),
+    dict(kind="pd", shape=(26, 5, 12), iters=6, mtv=0, nn=0, half=True),
     dict(kind="rof", shape=(9, 7, 11), iters=6, half=False),
     dict(kind="rof", shape=(10, 5, 9), iters=4, half=True),
 ]

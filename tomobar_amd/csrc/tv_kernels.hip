@@ -574,7 +574,18 @@ extern "C" int tomo_pdtv_pair_slab(int device, const float *in_dev, const float 
                                    int lo_planes, int hi_planes, float sigma, float tau, float lt, float theta,
                                    int methodTV, int nonneg, int half, void *stream)
 {
+    return tomo_pdtv_pair_slab_range(device, in_dev, u_in_dev, u_out_dev, p_in_dev, p_out_dev, dx, dy, nz_local, lo_planes,
+                                     hi_planes, 0, nz_local, sigma, tau, lt, theta, methodTV, nonneg, half, stream);
+}
+
+extern "C" int tomo_pdtv_pair_slab_range(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
+                                         const void *p_in_dev[3], void *p_out_dev[3], int dx, int dy, int nz_local,
+                                         int lo_planes, int hi_planes, int z_begin, int z_end, float sigma, float tau,
+                                         float lt, float theta, int methodTV, int nonneg, int half, void *stream)
+{
     TOMO_REQUIRE(device >= 0 && dx > 0 && dy > 0 && nz_local >= 2, "bad slab arguments (a slab needs >= 2 slices)");
+    TOMO_REQUIRE(z_begin >= 0 && z_begin <= z_end && z_end <= nz_local, "bad output plane range [%d, %d)", z_begin, z_end);
+    if (z_begin == z_end) return TOMO_OK;
     TOMO_REQUIRE((lo_planes == 0 || lo_planes == 2) && (hi_planes == 0 || hi_planes == 2),
                  "the two-iteration slab kernel needs 0 or 2 ghost planes on either side");
     TOMO_HIP(hipSetDevice(device));
@@ -583,11 +594,11 @@ extern "C" int tomo_pdtv_pair_slab(int device, const float *in_dev, const float 
     for (int c = 0; c < 3; ++c) { a.p_in[c] = p_in_dev[c]; a.p_out[c] = p_out_dev[c]; }
     a.dx = dx; a.dy = dy;
     a.planes = nz_local + lo_planes + hi_planes;
-    a.out_begin = lo_planes;
-    a.out_end = lo_planes + nz_local;
+    a.out_begin = lo_planes + z_begin;
+    a.out_end = lo_planes + z_end;
     a.first_is_edge = lo_planes ? 0 : 1;
     a.last_is_edge = hi_planes ? 0 : 1;
-    a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = nz_local;
+    a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = z_end - z_begin;
     hipStream_t st = as_stream(stream);
     tomo_prof_scope prof(PROF_PDTV, st, 1);
     return half ? pd_pair_launch<__half>(a, methodTV, nonneg, 0, st) : pd_pair_launch<float>(a, methodTV, nonneg, 0, st);

@@ -74,6 +74,25 @@ class SlabComm:
             for req in self.dist.batch_isend_irecv(ops):
                 req.wait()
 
+    def exchange_start(self, send_down, recv_down, send_up, recv_up):
+        """Asynchronous form of `exchange`: returns the requests.  With the nccl (RCCL) backend the transfers are ordered
+        after the work already queued on the current stream and run on RCCL's own stream, so kernels launched after this
+        call overlap with them; `exchange_wait` makes the current stream wait for their completion."""
+        ops = []
+        P2POp = self.dist.P2POp
+        if self.has_lo:
+            ops += [P2POp(self.dist.isend, t, self.rank - 1, self.group) for t in send_down]
+            ops += [P2POp(self.dist.irecv, t, self.rank - 1, self.group) for t in recv_down]
+        if self.has_hi:
+            ops += [P2POp(self.dist.isend, t, self.rank + 1, self.group) for t in send_up]
+            ops += [P2POp(self.dist.irecv, t, self.rank + 1, self.group) for t in recv_up]
+        return self.dist.batch_isend_irecv(ops) if ops else []
+
+    @staticmethod
+    def exchange_wait(reqs):
+        for req in reqs:
+            req.wait()
+
 
 # ------------------------------------------------------------------------------------------------ PD_TV on a slab
 class PdSlab:
@@ -112,10 +131,24 @@ class PdSlab:
         return self.local(self.U[self.cur])
 
     def pair(self, sigma, tau, lt, theta, methodTV, nonneg):
+        self.pair_range(sigma, tau, lt, theta, methodTV, nonneg, 0, self.nzl)
+        self.flip()
+
+    def pair_range(self, sigma, tau, lt, theta, methodTV, nonneg, z_begin, z_end):
+        """Two iterations for the local output planes [z_begin, z_end) only (buffer set cur -> cur ^ 1, no flip)."""
         i, o = self.cur, self.cur ^ 1
-        self.pair_fn(self.inp, self.U[i], self.U[o], self.P[i], self.P[o], self.dx, self.dy, self.nzl, self.lo, self.hi,
-                     sigma, tau, lt, theta, methodTV, nonneg, self.half)
-        self.cur = o
+        if z_end > z_begin:
+            self.pair_fn(self.inp, self.U[i], self.U[o], self.P[i], self.P[o], self.dx, self.dy, self.nzl, self.lo,
+                         self.hi, sigma, tau, lt, theta, methodTV, nonneg, self.half, (z_begin, z_end))
+
+    def flip(self):
+        self.cur ^= 1
+
+    def boundary_ranges(self):
+        """Local plane ranges whose results the neighbours wait for (two planes at an interior boundary) and the rest."""
+        b0 = 2 if self.has_lo else 0
+        b1 = self.nzl - (2 if self.has_hi else 0)
+        return ([(0, b0)] if self.has_lo else []) + ([(b1, self.nzl)] if self.has_hi else []), (b0, b1)
 
     def single(self, sigma, tau, lt, theta, methodTV, nonneg):
         """One iteration on the same arrays: the single-iteration kernel sees one ghost plane either side, i.e. the
@@ -187,19 +220,22 @@ def _hip_pd_step(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, has_lo, has_hi, sig
                                             int(bool(half)), ops.stream_ptr(inp)))
 
 
-def _hip_pd_pair(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, lo, hi, sigma, tau, lt, theta, methodTV, nonneg, half):
+def _hip_pd_pair(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, lo, hi, sigma, tau, lt, theta, methodTV, nonneg, half,
+                 zr=None):
     from . import _lib as L
     from . import ops
+    z0, z1 = zr if zr is not None else (0, nzl)
     with torch.cuda.device(inp.device):
-        L.check(L.lib().tomo_pdtv_pair_slab(inp.device.index, ops.ptr(inp), ops.ptr(u_in), ops.ptr(u_out), _ptr3(p_in),
-                                            _ptr3(p_out), dx, dy, nzl, int(lo), int(hi), float(sigma), float(tau),
-                                            float(lt), float(theta), int(bool(methodTV)), int(bool(nonneg)),
-                                            int(bool(half)), ops.stream_ptr(inp)))
+        L.check(L.lib().tomo_pdtv_pair_slab_range(inp.device.index, ops.ptr(inp), ops.ptr(u_in), ops.ptr(u_out),
+                                                  _ptr3(p_in), _ptr3(p_out), dx, dy, nzl, int(lo), int(hi), int(z0),
+                                                  int(z1), float(sigma), float(tau), float(lt), float(theta),
+                                                  int(bool(methodTV)), int(bool(nonneg)), int(bool(half)),
+                                                  ops.stream_ptr(inp)))
 
 
 def pd_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, methodTV=0, nonneg=0,
                lipschitz_const=8.0, half_precision=False, pair_fn: Optional[Callable] = None,
-               step_fn: Optional[Callable] = None, out=None):
+               step_fn: Optional[Callable] = None, out=None, overlap: bool = True):
     """PD_TV of a z-slab of a larger 3D volume; bit-identical to running PD_TV_cupy on the whole volume."""
     tau = np.float32(regularisation_parameter * 0.1)
     sigma = np.float32(1.0 / (lipschitz_const * tau))
@@ -210,8 +246,22 @@ def pd_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, m
     comm.exchange(st.input_send_down() + st.send_down(0)[:2], st.input_recv_down() + st.recv_down(0)[:2],
                   st.input_send_up() + st.send_up(0)[:2], st.input_recv_up() + st.recv_up(0)[:2])
     it = 0
+    edge_ranges, interior = st.boundary_ranges()
+    # Overlap: the planes the neighbours wait for are computed first (two thin launches), their exchange runs on RCCL's
+    # stream while the interior of the slab is computed, and the next pair starts when both are done.
+    overlap = overlap and bool(edge_ranges) and interior[1] - interior[0] >= 4
     while it < iterations:
         if iterations - it >= 2:
+            if overlap and it + 2 < iterations:
+                for z0, z1 in edge_ranges:
+                    st.pair_range(sigma, tau, lt, theta, methodTV, nonneg, z0, z1)
+                b = st.cur ^ 1
+                reqs = comm.exchange_start(st.send_down(b), st.recv_down(b), st.send_up(b), st.recv_up(b))
+                st.pair_range(sigma, tau, lt, theta, methodTV, nonneg, interior[0], interior[1])
+                st.flip()
+                comm.exchange_wait(reqs)
+                it += 2
+                continue
             st.pair(sigma, tau, lt, theta, methodTV, nonneg)
             it += 2
         else:
