@@ -66,3 +66,25 @@ def test_full_size_tv_on_z_invariant_volume(oracle, shape):
     got3 = ROF_TV_cupy(vol, 0.04, 3, 0.005, 0, False)
     want2 = torch.from_numpy(oracle.rof_tv(base, 0.04, 3, 0.005, False)).cuda()
     assert torch.equal(got3, want2.view(1, dy, dx).expand_as(got3)), float((got3 - want2.view(1, dy, dx)).abs().max())
+
+
+def test_config3_shape_projector_pair_against_oracle(oracle):
+    """BASELINE configs[3] geometry (2048^2 slices, 1500 angles, no subsets; a 70-slice piece of a GPU's z-slab): same
+    power-of-two slice scaling argument.  Exercises the two-tile detector, windows wider than 1024 columns and a ragged
+    last z-brick at that size."""
+    from tomobar_amd.projector import HipTools3D
+    n, nz, na = 2048, 70, 1500
+    angles = np.linspace(0, np.pi, na, endpoint=False)
+    H = HipTools3D(n, 0, nz, angles, -3.25, n, "gpu", 0, None)
+    P1 = oracle.Projector(1, n, n, angles, -3.25, 1)
+    rng = np.random.default_rng(3)
+    base_v = rng.random((1, n, n), dtype=np.float32)
+    sc = _scales(nz, "cuda")
+    got = H.forward(torch.from_numpy(base_v).cuda() * sc, None)
+    want = torch.from_numpy(P1.fp(base_v, None)).cuda() * sc
+    assert torch.equal(got, want), float((got - want).abs().max())
+    del got, want
+    base_s = rng.standard_normal((1, na, n)).astype(np.float32)
+    got = H.backward(torch.from_numpy(base_s).cuda() * sc, None)
+    want = torch.from_numpy(P1.bp(base_s, None)).cuda() * sc
+    assert torch.equal(got, want), float((got - want).abs().max())

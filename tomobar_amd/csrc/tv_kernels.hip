@@ -264,10 +264,10 @@ int pd_pair_launch(const PdArgs &a, int methodTV, int nonneg, int variant, hipSt
 {
 #define PD_X2(NN, AN)                                                                                          \
     /* measured, 1024^3 f32 duals, ms per iteration: 2x2 waves 5.60 | 2x1 5.74 | 4x1 6.20 | 4x2 7.10 | 8x1 8.28 */ \
-    (variant == 6 ? pd_zmarch_x2_launch<T, NN, AN, 4, 4, 2>(a, st)                                              \
+    (variant == 6 ? pd_zmarch_x2_launch<T, NN, AN, 4, 1, 2>(a, st)                                              \
                   : variant == 7 ? pd_zmarch_x2_launch<T, NN, AN, 4, 2, 1>(a, st)                               \
-                  : variant == 8 ? pd_zmarch_x2_launch<T, NN, AN, 4, 8, 1>(a, st)                               \
-                  : variant == 9 ? pd_zmarch_x2_launch<T, NN, AN, 4, 4, 1>(a, st)                               \
+                  : variant == 8 ? pd_zmarch_x2_launch<T, NN, AN, 4, 1, 4>(a, st)                               \
+                  : variant == 9 ? pd_zmarch_x2_launch<T, NN, AN, 4, 2, 4>(a, st)                               \
                                  : pd_zmarch_x2_launch<T, NN, AN, 4, 2, 2>(a, st))
     int rc;
     if (!nonneg && !methodTV) rc = PD_X2(false, false);
