@@ -67,3 +67,30 @@ def test_FBP_end_to_end_vs_oracle(oracle):
     Pp = oracle.Projector(nz, n, n + 10, angles)
     padded = np.pad(data, ((0, 0), (0, 0), (5, 5)), mode="edge")
     assert rel(rtp.FBP(d).cpu().numpy(), oracle.fbp(Pp, padded, 0.35)) < 1e-5
+
+
+@pytest.mark.gpu
+def test_2D_geometry_direct_methods_vs_oracle(oracle):
+    """BASELINE configs[0] shape of call: 2D geometry (DetectorsDimV=None), data [angles, detX], images [Y, X]
+    (reference: RecToolsDIR, methodsDIR.py:71-96,322-371) -- one slice through the same kernels."""
+    import torch
+    from tomobar_amd.methodsDIR_CuPy import RecToolsDIRCuPy
+    n, na = 64, 45
+    angles = np.linspace(0, np.pi, na, endpoint=False)
+    P = oracle.Projector(1, n, n, angles)
+    sino3 = oracle.shepp_logan_sino(n, 1, n, angles)                   # [1, angles, detX]
+    sino2 = np.ascontiguousarray(sino3[0])                             # [angles, detX]
+    rt = RecToolsDIRCuPy(n, 0, None, 0.0, angles, n, device_projector=0)
+    assert rt.geom == "2D"
+    rec = rt.FBP(torch.from_numpy(sino2).cuda(), recon_mask_radius=0.95)
+    want = oracle.circular_mask(oracle.fbp(P, np.ascontiguousarray(np.swapaxes(sino3, 0, 1)), 0.35), 0.95)[0]
+    assert rec.shape == (n, n) and rel(rec.cpu().numpy(), want) < 1e-5
+    # transposed labels
+    rec_t = rt.FBP(torch.from_numpy(np.ascontiguousarray(sino2.T)).cuda(), data_axes_labels_order=["detX", "angles"],
+                   recon_mask_radius=0.95)
+    assert np.array_equal(rec_t.cpu().numpy(), rec.cpu().numpy())
+    img = oracle.shepp_logan_3d(n, 1)[0]
+    fp = rt.FORWPROJ(torch.from_numpy(img).cuda())
+    assert fp.shape == (na, n) and np.array_equal(fp.cpu().numpy(), P.fp(img[None])[0])
+    bp = rt.BACKPROJ(torch.from_numpy(sino2).cuda())
+    assert bp.shape == (n, n) and rel(bp.cpu().numpy(), P.bp(sino3)[0]) < 1e-6

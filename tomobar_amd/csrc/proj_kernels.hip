@@ -6,16 +6,16 @@
 //   FP  ray-driven Joseph: step along the dominant axis, 2-tap linear interpolation along the other in-plane
 //       axis, zero outside the volume, scaled by the ray length per step.
 // MI355X mapping:
-//   * BP variant 0 ("tiled"): a 256-thread workgroup owns a 64(x) x 8(y) x 16(z) voxel brick.  The lanes of a
-//     wave walk x, so the detector coordinate is affine along the wave.  For a batch of 8 angles the
-//     [angle][z-quad][u] window of the sinogram that the brick can touch is staged in LDS as float4 over z:
-//     one ds_read_b128 per tap serves four slices, interpolation index/weights are computed once per
-//     (voxel column, angle) and reused by all 16 slices.  Workgroups are numbered so that each XCD's L2 sees
-//     one z-batch of sinogram rows at a time.
+//   * BP variant 0 ("brick", bp_brick.inl): a 256-thread workgroup owns a 32(x) x 16(y) x 16(z) voxel brick, a
+//     wave a 16 x 4 patch of it.  For a batch of 8 angles the [angle][z-quad][u] window of the sinogram that the
+//     brick can touch is staged in LDS as float4 over z: one ds_read_b128 per tap serves four slices,
+//     interpolation index/weights are computed once per (voxel column, angle) and reused by all 16 slices.
+//     Workgroups are numbered so that each XCD's L2 sees one z-batch of sinogram rows at a time.
+//   * BP variant 2 ("tiled"): the first LDS kernel (64 x 8 x 16 brick, lanes along x), kept for A/B runs.
 //   * BP variant 1 ("direct"): taps straight from global memory (L1/L2), 4 slices per thread.
-//   * FP: one lane per detector pixel, 4 slices per lane, sequential march (bit-identical to the oracle);
-//     x-stepping angles read an in-plane transposed copy of the volume so that the interpolation axis is
-//     always the contiguous one.
+//   * FP (fp_tiled.inl): one lane per detector pixel, 8 angles x 4 slices per lane, sequential march over the
+//     volume rows staged in LDS (bit-identical to the oracle); x-stepping angles read an in-plane transposed
+//     copy of the volume so that the interpolation axis is always the contiguous one.  Variant 1: no LDS.
 //   * epilogues: plain / residual (FP) and plain / FISTA step / FISTA step+momentum / ADMM z-update (BP).
 // No MFMA: there is no dense contraction on this path.
 #include "tomo_common.h"
