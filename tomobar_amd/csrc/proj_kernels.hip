@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 namespace {
 
@@ -383,10 +384,68 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
         }
     }
     if (tiled) {
+        // ---- wide form: one 1024-thread workgroup per detector row (see fp_tiled.inl), one launch per stepping AXIS: a
+        // whole-row window does not care about the sign of the detector slope, so the two classes of an axis (adjacent in
+        // the order table) are merged -- 37 angles make 5 groups of 8 instead of 3 + 3.  Chosen when the 256-pixel tiles
+        // would stage >= 1.25x what whole rows need (the 12-strided angles of an ordered subset), and it fits in LDS.
+        bool done[4] = {false, false, false, false};
+        {
+            static const int wide_env = getenv("TOMO_FP_WIDE") ? atoi(getenv("TOMO_FP_WIDE")) : -1;  // -1 auto
+            size_t axis_off = s.table_offset;
+            for (int d = 0; d < 2 && wide_env != 0 && g_variant_fp == 0 && a.nu >= 768; ++d) {
+                const int nc0 = s.n_class[2 * d], nc1 = s.n_class[2 * d + 1], nc = nc0 + nc1;
+                const size_t off_d = axis_off;
+                axis_off += nc;
+                if (nc == 0) continue;
+                if (s.wbound_wide[2 * d] < 0)
+                    s.wbound_wide[2 * d] = fp_window_bound(ctx->host_table.data() + s.table_offset,
+                                                           ctx->host_fp_order.data() + off_d, nc, ctx->n, ctx->nu, 1024);
+                const int wp = s.wbound_wide[2 * d];
+                const int nut_w = ceil_div(a.nu, 1024), nut = ceil_div(a.nu, 256);
+                const double cost_tiles = (double)nut * (ceil_div(nc0, FP_A) * std::max(s.wbound[2 * d], 0) +
+                                                         ceil_div(nc1, FP_A) * std::max(s.wbound[2 * d + 1], 0));
+                const double cost_rows = (double)nut_w * ceil_div(nc, FP_A) * wp;
+                const bool pays = wide_env == 1 || cost_tiles >= 1.25 * cost_rows;
+                const int passes_w = ceil_div(wp, 1024);
+                int kc_w = 4;
+                size_t smem_w = (size_t)2 * kc_w * wp * 16 + (size_t)a.n * 8;
+                if (smem_w > 160 * 1024) { kc_w = 2; smem_w = (size_t)2 * kc_w * wp * 16 + (size_t)a.n * 8; }
+                if (!(pays && passes_w <= 2 && smem_w <= 160 * 1024)) continue;
+                FpTiledArgs t;
+                t.src = d ? a.volT : a.vol;
+                t.tab = a.tab;
+                t.order = ctx->dev_fp_order + off_d;
+                t.n_class = nc;
+                t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
+                t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
+                t.wpitch = wp;
+                t.nut = nut_w;
+                t.ngroups = ceil_div(nc, FP_A);
+                t.nzb = ceil_div(a.nz, 4);
+                const long blocks_w = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
+                TOMO_REQUIRE(blocks_w <= 0x7fffffffL, "problem too large for one FP launch");
+#define FP_WIDE_LAUNCH(L8, RES)                                                                                        \
+    do {                                                                                                               \
+        auto launch = [&](auto kern) {                                                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)smem_w);                                                                    \
+            kern<<<(unsigned)blocks_w, 1024, smem_w, st>>>(t);                                                         \
+        };                                                                                                             \
+        if (passes_w == 1) launch(fp_tiled_kernel<L8, RES, 1, 4, true, 1024>);                                         \
+        else if (kc_w == 4) launch(fp_tiled_kernel<L8, RES, 2, 8, true, 1024>);                                        \
+        else launch(fp_tiled_kernel<L8, RES, 2, 4, true, 1024>);                                                       \
+    } while (0)
+                if (b) { if (l8) FP_WIDE_LAUNCH(true, true); else FP_WIDE_LAUNCH(false, true); }
+                else   { if (l8) FP_WIDE_LAUNCH(true, false); else FP_WIDE_LAUNCH(false, false); }
+#undef FP_WIDE_LAUNCH
+                TOMO_LAUNCH_CHECK();
+                done[2 * d] = done[2 * d + 1] = true;
+            }
+        }
         size_t order_off = s.table_offset;
         for (int c = 0; c < 4; ++c) {  // one launch per stepping class (x-stepping classes read the transposed copy)
             const int nc = s.n_class[c];
-            if (nc > 0) {
+            if (nc > 0 && !done[c]) {
                 FpTiledArgs t;
                 t.src = (c >> 1) ? a.volT : a.vol;
                 t.tab = a.tab;
@@ -406,45 +465,6 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 t.nzb = ceil_div(a.nz, 4);
                 const long blocks = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
                 TOMO_REQUIRE(blocks <= 0x7fffffffL, "problem too large for one FP launch");
-                // ---- wide form: one 1024-thread workgroup per detector row (see fp_tiled.inl).  Chosen when the 256-pixel
-                // tiles of a row would stage >= 1.25x what the whole row needs (ordered subsets), and it fits in LDS.
-                {
-                    static const int wide_env = getenv("TOMO_FP_WIDE") ? atoi(getenv("TOMO_FP_WIDE")) : -1;  // -1 auto
-                    if (wide_env != 0 && g_variant_fp == 0 && a.nu >= 768) {
-                        if (s.wbound_wide[c] < 0)
-                            s.wbound_wide[c] = fp_window_bound(ctx->host_table.data() + s.table_offset,
-                                                               ctx->host_fp_order.data() + order_off, nc, ctx->n, ctx->nu, 1024);
-                        const int wp = s.wbound_wide[c];
-                        const int nut_w = ceil_div(a.nu, 1024);
-                        const bool pays = wide_env == 1 || (double)t.nut * t.wpitch >= 1.25 * (double)nut_w * wp;
-                        const int passes_w = ceil_div(wp, 1024);
-                        int kc_w = 4;
-                        size_t smem_w = (size_t)2 * kc_w * wp * 16 + (size_t)a.n * 8;
-                        if (smem_w > 160 * 1024) { kc_w = 2; smem_w = (size_t)2 * kc_w * wp * 16 + (size_t)a.n * 8; }
-                        if (pays && passes_w <= 2 && smem_w <= 160 * 1024) {
-                            t.wpitch = wp;
-                            t.nut = nut_w;
-                            const long blocks_w = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
-#define FP_WIDE_LAUNCH(L8, RES)                                                                                        \
-    do {                                                                                                               \
-        auto launch = [&](auto kern) {                                                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)smem_w);                                                                    \
-            kern<<<(unsigned)blocks_w, 1024, smem_w, st>>>(t);                                                         \
-        };                                                                                                             \
-        if (passes_w == 1) launch(fp_tiled_kernel<L8, RES, 1, 4, true, 1024>);                                         \
-        else if (kc_w == 4) launch(fp_tiled_kernel<L8, RES, 2, 8, true, 1024>);                                        \
-        else launch(fp_tiled_kernel<L8, RES, 2, 4, true, 1024>);                                                       \
-    } while (0)
-                            if (b) { if (l8) FP_WIDE_LAUNCH(true, true); else FP_WIDE_LAUNCH(false, true); }
-                            else   { if (l8) FP_WIDE_LAUNCH(true, false); else FP_WIDE_LAUNCH(false, false); }
-#undef FP_WIDE_LAUNCH
-                            TOMO_LAUNCH_CHECK();
-                            order_off += nc;
-                            continue;
-                        }
-                    }
-                }
                 // Narrow windows (dense angle sets: <= 2 column passes) run the register-prefetch pipeline; wide
                 // windows (ordered subsets spread the angles of a group) run the synchronous form, whose small LDS
                 // footprint lets many workgroups per CU hide the staging latency.  Measured on MI355X:
