@@ -219,6 +219,25 @@ int tomo_roftv_iter_slab(int device, const float *in_dev, const float *u_in_dev,
  * `multiplier` (= 1/angles/nu in RecToolsDIRCuPy.FBP) folded into f.  Batched hipFFT; synchronises the stream. */
 int tomo_fbp_filter(int device, float *data_dev, size_t rows, int nu, float cutoff, float multiplier, void *stream);
 
+/* ---------------------------------------------------------------- Fourier reconstruction
+ * tomo_fourier_inv replaces the device side of RecToolsDIRCuPy.FOURIER_INV (tomobar/methodsDIR_CuPy.py:152-447: the
+ * stages _fbp_filtering :449-545, _setup_backprojection_input :645-683, _fft_and_interpolation :701-836,
+ * ifft_gathered_projections :851-897, unpad_reconstructed_data :920-967) and the kernels of
+ * tomobar/cuda_kernels/fft_us_kernels.cu.
+ *   data_dev  [nz][nproj][raw_n] float32, nz and raw_n even (the caller pads odd sizes as the reference does, :265-279)
+ *   out_dev   [out_z][out_size][out_size] float32; out_z = nz or nz-1 (odd original height)
+ *   n         detector width after horizontal padding (even), ne the oversampled filter width (:465-474)
+ *   unpad_m   first reconstructed column/row relative to -n/2 (unpad_recon_m, :933)
+ *   w_host    HOST array of ne/2+1 complex64 (re,im pairs): filter table x phase ramp of the rotation axis (:481-483)
+ *   theta_host HOST array of nproj float32 angles as the kernels see them (= -AnglesVec, :295)
+ *   m, mu     footprint half-width and Gaussian parameter (:321-322, :726-737)
+ *   center_size  min(center_size, 2n) of the reference (:290): >= 192 selects the circular-support gathering inside
+ *             the centre box and the square-footprint form outside it; < 192 the square-footprint form everywhere.
+ * Allocates its workspace per call, processes 128 slices per chunk, synchronises the stream before returning. */
+int tomo_fourier_inv(int device, const float *data_dev, float *out_dev, int nz, int out_z, int nproj, int raw_n,
+                     int n, int ne, int unpad_m, int out_size, const float *w_host, const float *theta_host,
+                     int m, float mu, int center_size, void *stream);
+
 /* kernel-variant selector for A/B measurement: name in {"bp","fp","pdtv","roftv"}; variant 0 = default */
 int tomo_set_variant(const char *kernel, int variant);
 

@@ -1,0 +1,441 @@
+// Fourier reconstruction on unequally spaced grids for gfx950.
+//
+// What is computed is fixed by the reference: tomobar/methodsDIR_CuPy.py:152-447 (driver) with the stages :449-545
+// (oversampled FBP filter), :645-683 (two slices -> one complex slice), :701-836 (1D FFT + gathering on the 2n x 2n
+// frequency grid), :851-897 (2D inverse FFT), :920-967 (unpadding x phi) and the kernels of
+// tomobar/cuda_kernels/fft_us_kernels.cu.  Restated on the CPU in oracle/fourier_oracle.py (pinned to the reference's own
+// output, tests/golden/fourier_golden.npz).
+//
+// How it is computed here (MI355X-first, not the reference's thread-per-(grid point, slice) kernels):
+//   * the slice-pair index z is the FASTEST dimension of everything between the 1D and the 2D FFT: polar samples
+//     g[angle][radius][z] and the frequency grid f[ky][kx][z], 64 slice pairs (128 slices) per chunk.  A wave owns one
+//     grid point at a time with one lane per slice pair: the geometry of the gathering (which angles pass within the
+//     support radius, which radial samples, the Gaussian weights -- the reference recomputes all of it per slice) is
+//     wave-uniform and computed once for 64 slice pairs, every sample fetch is one coalesced 512-byte row, and the sum
+//     runs in the reference's order (angles ascending, radius ascending), so the result is deterministic (the reference's
+//     small-detector path accumulates with atomics);
+//   * the 2D inverse FFT runs on that layout directly (hipFFT strided batch: stride 64, distance 1);
+//   * both checkerboard shifts are folded into the neighbouring kernels (store of the gathering, unpadding), the
+//     slice pairing + first shift into the crop of the filter output, the second 1D shift + 4/n scale into the transpose.
+// FFTs are library calls (hipFFT), like the reference's cuFFT via CuPy.  No MFMA: no dense contraction.
+#include "tomo_common.h"
+
+#include <hipfft/hipfft.h>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace {
+
+#define TOMO_FFT(expr)                                                                              \
+    do {                                                                                            \
+        hipfftResult r_ = (expr);                                                                   \
+        if (r_ != HIPFFT_SUCCESS) { rc = tomo_fail(TOMO_E_RUNTIME, "%s failed: hipfft status %d", #expr, (int)r_); goto done; } \
+    } while (0)
+#define TOMO_HIPG(expr)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) { rc = tomo_fail(TOMO_E_RUNTIME, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } \
+    } while (0)
+
+constexpr int FZ = 64;  // slice pairs per chunk = lanes of a wave
+constexpr float PI_F = 3.1415926535897932384626433832795f;  // fft_us_kernels.cu:2
+
+// ---- filter stage -------------------------------------------------------------------------------------------------
+// buf[r][j] = in[r][clamp(j - pad_m)]  (cp.pad(..., mode="edge"), methodsDIR_CuPy.py:522-530)
+__global__ __launch_bounds__(256) void pad_edge_kernel(const float *__restrict__ in, float *__restrict__ buf, size_t rows,
+                                                       int raw_n, int ne, int pad_m)
+{
+    const size_t total = rows * (size_t)ne, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t r = i / ne;
+        const int j = (int)(i - r * ne);
+        buf[i] = in[r * raw_n + min(max(j - pad_m, 0), raw_n - 1)];
+    }
+}
+
+__global__ __launch_bounds__(256) void mul_filter_kernel(float2 *spec, const float2 *__restrict__ w, size_t rows, int nh)
+{
+    const size_t total = rows * (size_t)nh, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const float2 g = w[i % nh], v = spec[i];
+        spec[i] = make_float2(g.x * v.x - g.y * v.y, g.x * v.y + g.y * v.x);
+    }
+}
+
+// Centre crop of the filtered rows, 1/ne of the unnormalised inverse transform, pairing of slices (2z, 2z+1) into one
+// complex slice and the first fftshift sign (r2c_c1dfftshift, fft_us_kernels.cu:519-548).
+// Rows of this sub-chunk: row = (slice_local * nproj + p), slice_local = row0_slice + ...; datac[z][p][x]
+__global__ __launch_bounds__(256) void crop_pair_kernel(const float *__restrict__ buf, float2 *__restrict__ datac, size_t rows,
+                                                        size_t row_first, int nproj, int n, int ne, int unpad_m, float inv_ne)
+{
+    const size_t total = rows * (size_t)n, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t r = i / n;
+        const int x = (int)(i - r * n);
+        const size_t row = row_first + r;           // row in the chunk: slice_local * nproj + p
+        const size_t sl = row / nproj, p = row - sl * nproj;
+        const float sgn = (x & 1) ? 1.0f : -1.0f;
+        const float v = buf[r * ne + unpad_m + x] * inv_ne * sgn;
+        float *dst = reinterpret_cast<float *>(datac + ((sl >> 1) * nproj + p) * n + x);
+        dst[sl & 1] = v;
+    }
+}
+
+// g[p][x][z] = datac[z][p][x] * (4/n) * sign(x)   (c1dfftshift, fft_us_kernels.cu:550-577), z-fastest, zero beyond zc
+__global__ __launch_bounds__(256) void transpose_scale_kernel(const float2 *__restrict__ datac, float2 *__restrict__ g, int zc,
+                                                              int nproj, int n, float constant)
+{
+    __shared__ float2 tile[FZ][65];
+    const int p = blockIdx.y, x0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int z = wave; z < FZ; z += 4) {
+        float2 v = make_float2(0.0f, 0.0f);
+        const int x = x0 + lane;
+        if (z < zc && x < n) {
+            v = datac[((size_t)z * nproj + p) * n + x];
+            const float sgn = (x & 1) ? 1.0f : -1.0f;
+            v.x = v.x * constant * sgn;
+            v.y = v.y * constant * sgn;
+        }
+        tile[z][lane] = v;
+    }
+    __syncthreads();
+    for (int xx = wave; xx < 64; xx += 4) {
+        const int x = x0 + xx;
+        if (x < n) g[((size_t)p * n + x) * FZ + lane] = tile[lane][xx];
+    }
+}
+
+// ---- gathering ----------------------------------------------------------------------------------------------------
+struct GatherArgs {
+    const float2 *g;       // [nproj][n][FZ]
+    float2 *f;             // [2n][2n][FZ]
+    const float *ct, *st;  // cos / sin of theta[j]          (original angle order)
+    const float *sth;      // theta sorted ascending
+    const int *order;      // original index of the k-th smallest theta
+    int nproj, n, m, center_size, use_center;
+    float mu;
+};
+
+__device__ __forceinline__ float clamp_half(float v) { return v >= 0.5f ? 0.5f - 1e-5f : v; }
+
+__device__ __forceinline__ int lower_bound_f(const float *a, int n, float v)  // first index with a[i] >= v
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// One grid point in the reference's "centre" form (gather_kernel_center, fft_us_kernels.cu:376-517): circular support.
+__device__ __forceinline__ void gather_center_point(const GatherArgs &a, int tx, int ty, int lane, float2 &acc)
+{
+    const int n = a.n;
+    const float coeff0 = PI_F / a.mu, coeff1 = -PI_F * PI_F / a.mu;
+    const float fs2 = (float)(4 * n) * (float)n;
+    const float radius_2 = 2.0f * ((float)a.m + 0.5f) * ((float)a.m + 0.5f) / fs2;
+    const float px = (float)(tx - n) / (float)(2 * n), py = (float)(n - ty) / (float)(2 * n);
+    const float rho2 = px * px + py * py;
+
+    auto one_angle = [&](int pi) {
+        const float costheta = a.ct[pi], sintheta = a.st[pi];
+        const float vx = 0.5f * costheta, vy = 0.5f * sintheta;
+        const float dot = vx * px + vy * py;
+        const float mx = dot * vx / 0.25f, my = dot * vy / 0.25f;
+        const float d2 = (mx - px) * (mx - px) + (my - py) * (my - py);
+        if (!(radius_2 >= d2)) return;
+        const float dti = sqrtf(radius_2 - d2);
+        int rmin, rmax;
+        if (fabsf(vx) > fabsf(vy)) {
+            rmin = n / 2 - 1 + (int)floorf((mx - dti * vx / 0.5f) / (2.0f * vx / (float)n));
+            rmax = n / 2 + 1 + (int)floorf((mx + dti * vx / 0.5f) / (2.0f * vx / (float)n));
+        } else {
+            rmin = n / 2 - 1 + (int)floorf((my - dti * vy / 0.5f) / (2.0f * vy / (float)n));
+            rmax = n / 2 + 1 + (int)floorf((my + dti * vy / 0.5f) / (2.0f * vy / (float)n));
+        }
+        if (rmin > rmax) { const int t = rmax; rmax = rmin; rmin = t; }
+        rmin = min(max(rmin, 0), n - 1);
+        rmax = min(max(rmax, 0), n - 1);
+        const float2 *row = a.g + ((size_t)pi * n) * FZ + lane;
+        for (int ri = rmin; ri < rmax; ++ri) {
+            const float rr = (float)(ri - n / 2) / (float)n;
+            const float x0 = clamp_half(rr * costheta), y0 = clamp_half(rr * sintheta);
+            const float w0 = px - x0, w1 = py - y0;
+            const float w = coeff0 * __expf(coeff1 * (w0 * w0 + w1 * w1));
+            const float2 v = row[(size_t)ri * FZ];
+            acc.x += v.x * w;
+            acc.y += v.y * w;
+        }
+    };
+
+    if (radius_2 >= rho2) {  // every ray passes within the support radius
+        for (int k = 0; k < a.nproj; ++k) one_angle(a.order[k]);
+        return;
+    }
+    // rays within asin(R / rho) of the direction of the point, modulo pi; a small margin, the exact test is in one_angle
+    const float rho = sqrtf(rho2);
+    const float delta = asinf(fminf(sqrtf(radius_2) / rho, 1.0f)) + 2.0e-3f;
+    if (2.0f * delta >= PI_F) {
+        for (int k = 0; k < a.nproj; ++k) one_angle(a.order[k]);
+        return;
+    }
+    const float phi = atan2f(py, px);
+    const float tmin = a.sth[0], tmax = a.sth[a.nproj - 1];
+    // centres phi + j*pi, ascending j, such that [c - delta, c + delta] meets [tmin, tmax]
+    int j = (int)ceilf((tmin - delta - phi) / PI_F);
+    int done_until = 0;  // sorted indices below this have been visited (keeps the ranges disjoint)
+    for (;; ++j) {
+        const float c = phi + (float)j * PI_F;
+        if (c - delta > tmax) break;
+        int k0 = max(lower_bound_f(a.sth, a.nproj, c - delta), done_until);
+        const int k1 = lower_bound_f(a.sth, a.nproj, c + delta);  // exclusive
+        for (int k = k0; k < k1; ++k) one_angle(a.order[k]);
+        done_until = max(done_until, k1);
+    }
+}
+
+// One grid point in the reference's scatter form seen from the receiving side (gather_kernel / gather_kernel_partial,
+// fft_us_kernels.cu:5-113): a sample contributes when the point lies in its (2m+1)^2 footprint (periodic wrap).
+__device__ __forceinline__ void gather_square_point(const GatherArgs &a, int ix, int iy, int lane, float2 &acc)
+{
+    const int n = a.n, m = a.m, two_n = 2 * n;
+    const float coeff0 = PI_F / a.mu, coeff1 = -PI_F * PI_F / a.mu;
+    const int l0 = ix - n, l1 = iy - n;  // unwrapped cell indices in [-n, n)
+    for (int pi = 0; pi < a.nproj; ++pi) {
+        const float costheta = a.ct[pi], sintheta = a.st[pi];
+        // dominant axis of the ray: 2n * r * c must land in [L - m, L + m + 1) for an image L = l + 2n*k of the cell
+        const bool xdom = fabsf(costheta) >= fabsf(sintheta);
+        const float c = xdom ? costheta : -sintheta;
+        const int l = xdom ? l0 : l1;
+        int prev_hi = -1;
+        const float sgn = c >= 0.0f ? 1.0f : -1.0f;
+        // images in the order of increasing r
+        for (int kk = -1; kk <= 1; ++kk) {
+            const int k = c >= 0.0f ? kk : -kk;
+            const float L = (float)(l + two_n * k);
+            float r_lo = (L - (float)m) / ((float)two_n * c), r_hi = (L + (float)m + 1.0f) / ((float)two_n * c);
+            if (sgn < 0.0f) { const float t = r_lo; r_lo = r_hi; r_hi = t; }
+            if (r_hi < -0.52f || r_lo > 0.52f) continue;
+            int t_lo = (int)floorf((float)(n / 2) + (float)n * r_lo) - 2, t_hi = (int)ceilf((float)(n / 2) + (float)n * r_hi) + 2;
+            t_lo = max(max(t_lo, 0), prev_hi + 1);
+            t_hi = min(t_hi, n - 1);
+            if (t_hi < t_lo) continue;
+            prev_hi = t_hi;
+            const float2 *row = a.g + ((size_t)pi * n) * FZ + lane;
+            for (int tx = t_lo; tx <= t_hi; ++tx) {
+                const float rr = (float)(tx - n / 2) / (float)n;
+                const float x0 = clamp_half(rr * costheta), y0 = clamp_half(-rr * sintheta);
+                const int e0 = (int)floorf((float)two_n * x0), e1 = (int)floorf((float)two_n * y0);
+                // footprint offset that maps onto this cell modulo 2n, if any
+                int d0 = (ix - e0 + m - 3 * n) % two_n, d1 = (iy - e1 + m - 3 * n) % two_n;
+                if (d0 < 0) d0 += two_n;
+                if (d1 < 0) d1 += two_n;
+                if (d0 > 2 * m || d1 > 2 * m) continue;
+                const float w0 = (float)(e0 - m + d0) / (float)two_n - x0, w1 = (float)(e1 - m + d1) / (float)two_n - y0;
+                const float w = coeff0 * __expf(coeff1 * (w0 * w0 + w1 * w1));
+                const float2 v = row[(size_t)tx * FZ];
+                acc.x += w * v.x;
+                acc.y += w * v.y;
+            }
+        }
+    }
+}
+
+constexpr int GP = 8;  // grid points per wave
+
+__global__ __launch_bounds__(256) void gather_kernel(GatherArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int two_n = 2 * a.n;
+    const int iy = blockIdx.y;
+    const int x_first = (blockIdx.x * 4 + wave) * GP;
+    const int chs = a.center_size / 2, base = max(0, a.n - chs);
+    for (int q = 0; q < GP; ++q) {
+        const int ix = x_first + q;
+        if (ix >= two_n) break;
+        float2 acc = make_float2(0.0f, 0.0f);
+        const bool in_box = a.use_center && ix >= base && ix < base + a.center_size && iy >= base && iy < base + a.center_size;
+        if (in_box) gather_center_point(a, ix, iy, lane, acc);
+        else gather_square_point(a, ix, iy, lane, acc);
+        // first c2dfftshift (fft_us_kernels.cu:579-603) folded into the store
+        const float chk = ((ix ^ iy) & 1) ? -1.0f : 1.0f;
+        a.f[((size_t)iy * two_n + ix) * FZ + lane] = make_float2(acc.x * chk, acc.y * chk);
+    }
+}
+
+// ---- unpadding: second c2dfftshift, 1/(2n)^2 of the unnormalised inverse transform, phi, slice un-pairing -----------
+// out[z0*2 + 2z (+1)][ry][rx]   (unpadding_mul_phi, fft_us_kernels.cu:605-658)
+__global__ __launch_bounds__(256) void unpad_kernel(const float2 *__restrict__ f, float *__restrict__ out, int n, int um, int size,
+                                                    int zc, int slice0, int out_z, float mu, float phi_scale, float inv_norm)
+{
+    __shared__ float2 tile[32][FZ + 1];
+    const int ry = blockIdx.y, rx0 = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int two_n = 2 * n;
+    const int ty = n / 2 + um + ry;
+    for (int xx = wave; xx < 32; xx += 4) {
+        const int rxu = rx0 + xx;
+        float2 v = make_float2(0.0f, 0.0f);
+        if (rxu < size) {
+            const int tx = n / 2 + um + rxu;
+            v = f[((size_t)ty * two_n + tx) * FZ + lane];
+            const float chk = ((tx ^ ty) & 1) ? -1.0f : 1.0f;
+            const float dx = -0.5f + (float)(um + rxu) * 1.0f / (float)n, dy = -0.5f + (float)(um + ry) * 1.0f / (float)n;
+            const float phi = expf(mu * (float)(n * n) * (dx * dx + dy * dy)) * phi_scale;
+            v.x = v.x * inv_norm * chk * phi;
+            v.y = v.y * inv_norm * chk * phi;
+        }
+        tile[xx][lane] = v;
+    }
+    __syncthreads();
+    // 2*FZ output slices x 32 columns
+    for (int s = threadIdx.x >> 5; s < 2 * FZ; s += 8) {
+        const int z = s >> 1, xx = threadIdx.x & 31, rxu = rx0 + xx;
+        const int slice = slice0 + s;
+        if (z < zc && rxu < size && slice < out_z) {
+            const float2 v = tile[xx][z];
+            out[((size_t)slice * size + ry) * size + rxu] = (s & 1) ? v.y : v.x;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_dev, int nz, int out_z, int nproj, int raw_n,
+                                int n, int ne, int unpad_m, int out_size, const float *w_host, const float *theta_host,
+                                int m, float mu, int center_size, void *stream)
+{
+    TOMO_REQUIRE(device >= 0 && data_dev && out_dev && w_host && theta_host, "NULL argument");
+    TOMO_REQUIRE(nz >= 2 && nz % 2 == 0 && raw_n >= 2 && raw_n % 2 == 0 && n >= raw_n && n % 2 == 0 && ne >= n && ne % 2 == 0,
+                 "detector sizes must be even (the caller pads odd sizes) and raw_n <= n <= ne");
+    TOMO_REQUIRE(nproj >= 1 && m >= 1 && m <= 64 && mu > 0.0f && out_size >= 1 && unpad_m >= 0 && unpad_m + out_size <= n,
+                 "bad Fourier reconstruction parameters");
+    TOMO_REQUIRE(out_z >= 1 && out_z <= nz && center_size >= 0 && center_size <= 2 * n, "bad output / centre size");
+    TOMO_REQUIRE(2L * n <= 32768, "detector too wide for the Fourier reconstruction grid");
+    TOMO_HIP(hipSetDevice(device));
+    hipStream_t st = as_stream(stream);
+    int rc = TOMO_OK;
+
+    const int nzh = nz / 2, nh = ne / 2 + 1, two_n = 2 * n;
+    const int zc_max = std::min(nzh, FZ);
+    // filter sub-chunks: at most ~64 Mi floats in the padded buffer
+    const size_t chunk_rows = (size_t)2 * zc_max * nproj;
+    const size_t rows_sub = std::max<size_t>(1, std::min<size_t>(chunk_rows, ((size_t)64 << 20) / ne));
+    const size_t bytes_buf = rows_sub * (size_t)ne * sizeof(float);
+    const size_t bytes_spec = rows_sub * (size_t)nh * sizeof(float2);
+    const size_t bytes_datac = (size_t)zc_max * nproj * n * sizeof(float2);
+    const size_t bytes_g = (size_t)nproj * n * FZ * sizeof(float2);
+    const size_t bytes_f = (size_t)two_n * two_n * FZ * sizeof(float2);
+    const size_t bytes_tab = ((size_t)nh * sizeof(float2) + (size_t)nproj * 4 * sizeof(float) + (size_t)nproj * sizeof(int) + 1024);
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    char *ws = nullptr;
+    hipfftHandle p_r2c = 0, p_c2r = 0, p_c2c = 0, p_2d = 0;
+    size_t rows_planned = 0;
+    int zc_planned = 0;
+    {
+        const size_t total = al(bytes_buf) + al(bytes_spec) + al(bytes_datac) + al(bytes_g) + al(bytes_f) + al(bytes_tab);
+        hipError_t e = hipMalloc((void **)&ws, total);
+        if (e != hipSuccess) return tomo_fail(TOMO_E_NOMEM, "Fourier reconstruction workspace of %zu bytes: %s", total, hipGetErrorString(e));
+    }
+    {
+        float *buf = (float *)ws;
+        float2 *spec = (float2 *)(ws + al(bytes_buf));
+        float2 *datac = (float2 *)((char *)spec + al(bytes_spec));
+        float2 *g = (float2 *)((char *)datac + al(bytes_datac));
+        float2 *f = (float2 *)((char *)g + al(bytes_g));
+        char *tab = (char *)f + al(bytes_f);
+        float2 *w_dev = (float2 *)tab;
+        float *ct = (float *)(tab + al((size_t)nh * sizeof(float2)));
+        float *sn = ct + nproj, *sth = sn + nproj;
+        int *order = (int *)(sth + nproj);
+
+        // host-side tables: cos / sin per angle, angles sorted ascending (stable) with their original indices
+        std::vector<float> h_ct(nproj), h_sn(nproj), h_sth(nproj);
+        std::vector<int> h_order(nproj);
+        for (int i = 0; i < nproj; ++i) { h_ct[i] = cosf(theta_host[i]); h_sn[i] = sinf(theta_host[i]); h_order[i] = i; }
+        std::stable_sort(h_order.begin(), h_order.end(), [&](int p, int q) { return theta_host[p] < theta_host[q]; });
+        for (int i = 0; i < nproj; ++i) h_sth[i] = theta_host[h_order[i]];
+        TOMO_HIPG(hipMemcpyAsync(w_dev, w_host, (size_t)nh * sizeof(float2), hipMemcpyHostToDevice, st));
+        TOMO_HIPG(hipMemcpyAsync(ct, h_ct.data(), nproj * sizeof(float), hipMemcpyHostToDevice, st));
+        TOMO_HIPG(hipMemcpyAsync(sn, h_sn.data(), nproj * sizeof(float), hipMemcpyHostToDevice, st));
+        TOMO_HIPG(hipMemcpyAsync(sth, h_sth.data(), nproj * sizeof(float), hipMemcpyHostToDevice, st));
+        TOMO_HIPG(hipMemcpyAsync(order, h_order.data(), nproj * sizeof(int), hipMemcpyHostToDevice, st));
+        TOMO_HIPG(hipStreamSynchronize(st));  // host vectors go out of scope at the end of this block only; be explicit
+
+        {   // 2D inverse plan on the z-fastest layout
+            int dims[2] = {two_n, two_n};
+            TOMO_FFT(hipfftPlanMany(&p_2d, 2, dims, dims, FZ, 1, dims, FZ, 1, HIPFFT_C2C, FZ));
+            TOMO_FFT(hipfftSetStream(p_2d, st));
+        }
+        const int pad_m = ne / 2 - raw_n / 2, crop_m = ne / 2 - n / 2;
+        const float phi_scale = (float)(1 - n % 4) / (float)nproj;
+        for (int c0 = 0; c0 < nzh; c0 += FZ) {
+            const int zc = std::min(FZ, nzh - c0);
+            const size_t rows = (size_t)2 * zc * nproj;
+            // ---- STEP 0: filter (methodsDIR_CuPy.py:449-545), output paired + shifted into datac[z][p][x]
+            for (size_t r0 = 0; r0 < rows; r0 += rows_sub) {
+                const size_t rs = std::min(rows_sub, rows - r0);
+                if (rs != rows_planned) {
+                    if (p_r2c) { (void)hipfftDestroy(p_r2c); p_r2c = 0; }
+                    if (p_c2r) { (void)hipfftDestroy(p_c2r); p_c2r = 0; }
+                    int len[1] = {ne};
+                    TOMO_FFT(hipfftPlanMany(&p_r2c, 1, len, nullptr, 1, ne, nullptr, 1, nh, HIPFFT_R2C, (int)rs));
+                    TOMO_FFT(hipfftPlanMany(&p_c2r, 1, len, nullptr, 1, nh, nullptr, 1, ne, HIPFFT_C2R, (int)rs));
+                    TOMO_FFT(hipfftSetStream(p_r2c, st));
+                    TOMO_FFT(hipfftSetStream(p_c2r, st));
+                    rows_planned = rs;
+                }
+                const float *src = data_dev + ((size_t)2 * c0 * nproj + r0) * raw_n;
+                pad_edge_kernel<<<2048, 256, 0, st>>>(src, buf, rs, raw_n, ne, pad_m);
+                TOMO_FFT(hipfftExecR2C(p_r2c, buf, (hipfftComplex *)spec));
+                mul_filter_kernel<<<2048, 256, 0, st>>>(spec, w_dev, rs, nh);
+                TOMO_FFT(hipfftExecC2R(p_c2r, (hipfftComplex *)spec, buf));
+                crop_pair_kernel<<<2048, 256, 0, st>>>(buf, datac, rs, r0, nproj, n, ne, crop_m, 1.0f / (float)ne);
+            }
+            // ---- STEP 1: 1D FFT along the detector (methodsDIR_CuPy.py:723-724)
+            if (zc != zc_planned) {
+                if (p_c2c) { (void)hipfftDestroy(p_c2c); p_c2c = 0; }
+                int len[1] = {n};
+                TOMO_FFT(hipfftPlanMany(&p_c2c, 1, len, nullptr, 1, n, nullptr, 1, n, HIPFFT_C2C, zc * nproj));
+                TOMO_FFT(hipfftSetStream(p_c2c, st));
+                zc_planned = zc;
+            }
+            TOMO_FFT(hipfftExecC2C(p_c2c, (hipfftComplex *)datac, (hipfftComplex *)datac, HIPFFT_FORWARD));
+            {
+                dim3 grid(ceil_div(n, 64), nproj);
+                transpose_scale_kernel<<<grid, 256, 0, st>>>(datac, g, zc, nproj, n, 4.0f / (float)n);
+            }
+            // ---- STEP 2: gathering on the 2n x 2n frequency grid (methodsDIR_CuPy.py:760-836)
+            {
+                GatherArgs ga;
+                ga.g = g; ga.f = f; ga.ct = ct; ga.st = sn; ga.sth = sth; ga.order = order;
+                ga.nproj = nproj; ga.n = n; ga.m = m; ga.mu = mu;
+                ga.center_size = center_size;
+                ga.use_center = center_size >= 192 ? 1 : 0;  // _CENTER_SIZE_MIN, methodsDIR_CuPy.py:23
+                dim3 grid(ceil_div(two_n, 4 * GP), two_n);
+                gather_kernel<<<grid, 256, 0, st>>>(ga);
+            }
+            // ---- STEP 3: 2D inverse FFT (methodsDIR_CuPy.py:851-897); the shifts live in the neighbouring kernels
+            TOMO_FFT(hipfftExecC2C(p_2d, (hipfftComplex *)f, (hipfftComplex *)f, HIPFFT_BACKWARD));
+            // ---- STEP 4: unpadding x phi (methodsDIR_CuPy.py:920-967)
+            {
+                dim3 grid(ceil_div(out_size, 32), out_size);
+                unpad_kernel<<<grid, 256, 0, st>>>(f, out_dev, n, unpad_m, out_size, zc, 2 * c0, out_z, mu, phi_scale,
+                                                   1.0f / ((float)two_n * (float)two_n));
+            }
+            TOMO_HIPG(hipGetLastError());
+        }
+        TOMO_HIPG(hipStreamSynchronize(st));  // the workspace and the plans are released below
+    }
+done:
+    if (p_r2c) (void)hipfftDestroy(p_r2c);
+    if (p_c2r) (void)hipfftDestroy(p_c2r);
+    if (p_c2c) (void)hipfftDestroy(p_c2c);
+    if (p_2d) (void)hipfftDestroy(p_2d);
+    if (ws) { (void)hipStreamSynchronize(st); (void)hipFree(ws); }
+    return rc;
+}
