@@ -8,13 +8,14 @@
 //
 // How it is computed here (MI355X-first, not the reference's thread-per-(grid point, slice) kernels):
 //   * the slice-pair index z is the FASTEST dimension of everything between the 1D and the 2D FFT: polar samples
-//     g[angle][radius][z] and the frequency grid f[ky][kx][z], 64 slice pairs (128 slices) per chunk.  A wave owns one
+//     g[angle][radius][z] 64 slice pairs (128 slices) per chunk.  A wave owns one
 //     grid point at a time with one lane per slice pair: the geometry of the gathering (which angles pass within the
 //     support radius, which radial samples, the Gaussian weights -- the reference recomputes all of it per slice) is
 //     wave-uniform and computed once for 64 slice pairs, every sample fetch is one coalesced 512-byte row, and the sum
 //     runs in the reference's order (angles ascending, radius ascending), so the result is deterministic (the reference's
 //     small-detector path accumulates with atomics);
-//   * the 2D inverse FFT runs on that layout directly (hipFFT strided batch: stride 64, distance 1);
+//   * a wave leaves its 16 grid points x 64 slice pairs through an LDS transpose, as 128-byte lines of f[z][ky][kx], so
+//     the 2D inverse FFT is a plain contiguous batch (the strided form cost 2.2x the gathering in hipFFT transposes);
 //   * both checkerboard shifts are folded into the neighbouring kernels (store of the gathering, unpadding), the
 //     slice pairing + first shift into the crop of the filter output, the second 1D shift + 4/n scale into the transpose.
 // FFTs are library calls (hipFFT), like the reference's cuFFT via CuPy.  No MFMA: no dense contraction.
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void transpose_scale_kernel(const float2 *__re
 // ---- gathering ----------------------------------------------------------------------------------------------------
 struct GatherArgs {
     const float2 *g;       // [nproj][n][FZ]
-    float2 *f;             // [2n][2n][FZ]
+    float2 *f;             // [zc][2n][2n]  (layout of the 2D FFT)
     const float *ct, *st;  // cos / sin of theta[j]          (original angle order)
     const float *sth;      // theta sorted ascending
     const int *order;      // original index of the k-th smallest theta
@@ -245,10 +246,11 @@ __device__ __forceinline__ void gather_square_point(const GatherArgs &a, int ix,
     }
 }
 
-constexpr int GP = 8;  // grid points per wave
+constexpr int GP = 8;   // grid points per wave: 8 consecutive kx = one 64-byte sector of the frequency grid per slice pair
 
-__global__ __launch_bounds__(256) void gather_kernel(GatherArgs a)
+__global__ __launch_bounds__(256) void gather_kernel(GatherArgs a, int zc)
 {
+    __shared__ float2 stage[4][GP][FZ + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int two_n = 2 * a.n;
     const int iy = blockIdx.y;
@@ -256,51 +258,44 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a)
     const int chs = a.center_size / 2, base = max(0, a.n - chs);
     for (int q = 0; q < GP; ++q) {
         const int ix = x_first + q;
-        if (ix >= two_n) break;
         float2 acc = make_float2(0.0f, 0.0f);
-        const bool in_box = a.use_center && ix >= base && ix < base + a.center_size && iy >= base && iy < base + a.center_size;
-        if (in_box) gather_center_point(a, ix, iy, lane, acc);
-        else gather_square_point(a, ix, iy, lane, acc);
+        if (ix < two_n) {
+            const bool in_box = a.use_center && ix >= base && ix < base + a.center_size && iy >= base && iy < base + a.center_size;
+            if (in_box) gather_center_point(a, ix, iy, lane, acc);
+            else gather_square_point(a, ix, iy, lane, acc);
+        }
         // first c2dfftshift (fft_us_kernels.cu:579-603) folded into the store
         const float chk = ((ix ^ iy) & 1) ? -1.0f : 1.0f;
-        a.f[((size_t)iy * two_n + ix) * FZ + lane] = make_float2(acc.x * chk, acc.y * chk);
+        stage[wave][q][lane] = make_float2(acc.x * chk, acc.y * chk);
+    }
+    // the wave's GP x 64 results leave in the layout of the 2D FFT, f[z][ky][kx]: 4 slice pairs x 16 kx per store
+    // (same-wave LDS exchange: no barrier needed, the compiler orders the ds operations of a wave)
+    __builtin_amdgcn_wave_barrier();
+    const int qx = lane & (GP - 1), zq = lane / GP;
+#pragma unroll 4
+    for (int z0 = 0; z0 < FZ; z0 += 64 / GP) {
+        const int z = z0 + zq, ix = x_first + qx;
+        if (z < zc && ix < two_n) a.f[((size_t)z * two_n + iy) * two_n + ix] = stage[wave][qx][z];
     }
 }
 
 // ---- unpadding: second c2dfftshift, 1/(2n)^2 of the unnormalised inverse transform, phi, slice un-pairing -----------
-// out[z0*2 + 2z (+1)][ry][rx]   (unpadding_mul_phi, fft_us_kernels.cu:605-658)
+// out[slice0 + 2z (+1)][ry][rx] from f[z][ky][kx]   (unpadding_mul_phi, fft_us_kernels.cu:605-658)
 __global__ __launch_bounds__(256) void unpad_kernel(const float2 *__restrict__ f, float *__restrict__ out, int n, int um, int size,
-                                                    int zc, int slice0, int out_z, float mu, float phi_scale, float inv_norm)
+                                                    int slice0, int out_z, float mu, float phi_scale, float inv_norm)
 {
-    __shared__ float2 tile[32][FZ + 1];
-    const int ry = blockIdx.y, rx0 = blockIdx.x * 32;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rxu = blockIdx.x * 256 + threadIdx.x, ry = blockIdx.y, z = blockIdx.z;
+    if (rxu >= size) return;
     const int two_n = 2 * n;
-    const int ty = n / 2 + um + ry;
-    for (int xx = wave; xx < 32; xx += 4) {
-        const int rxu = rx0 + xx;
-        float2 v = make_float2(0.0f, 0.0f);
-        if (rxu < size) {
-            const int tx = n / 2 + um + rxu;
-            v = f[((size_t)ty * two_n + tx) * FZ + lane];
-            const float chk = ((tx ^ ty) & 1) ? -1.0f : 1.0f;
-            const float dx = -0.5f + (float)(um + rxu) * 1.0f / (float)n, dy = -0.5f + (float)(um + ry) * 1.0f / (float)n;
-            const float phi = expf(mu * (float)(n * n) * (dx * dx + dy * dy)) * phi_scale;
-            v.x = v.x * inv_norm * chk * phi;
-            v.y = v.y * inv_norm * chk * phi;
-        }
-        tile[xx][lane] = v;
-    }
-    __syncthreads();
-    // 2*FZ output slices x 32 columns
-    for (int s = threadIdx.x >> 5; s < 2 * FZ; s += 8) {
-        const int z = s >> 1, xx = threadIdx.x & 31, rxu = rx0 + xx;
-        const int slice = slice0 + s;
-        if (z < zc && rxu < size && slice < out_z) {
-            const float2 v = tile[xx][z];
-            out[((size_t)slice * size + ry) * size + rxu] = (s & 1) ? v.y : v.x;
-        }
-    }
+    const int tx = n / 2 + um + rxu, ty = n / 2 + um + ry;
+    float2 v = f[((size_t)z * two_n + ty) * two_n + tx];
+    const float chk = ((tx ^ ty) & 1) ? -1.0f : 1.0f;
+    const float dx = -0.5f + (float)(um + rxu) * 1.0f / (float)n, dy = -0.5f + (float)(um + ry) * 1.0f / (float)n;
+    const float phi = expf(mu * (float)(n * n) * (dx * dx + dy * dy)) * phi_scale;
+    const int s0 = slice0 + 2 * z;
+    const size_t o = ((size_t)s0 * size + ry) * size + rxu;
+    if (s0 < out_z) out[o] = v.x * inv_norm * chk * phi;
+    if (s0 + 1 < out_z) out[o + (size_t)size * size] = v.y * inv_norm * chk * phi;
 }
 
 }  // namespace
@@ -329,7 +324,7 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
     const size_t bytes_spec = rows_sub * (size_t)nh * sizeof(float2);
     const size_t bytes_datac = (size_t)zc_max * nproj * n * sizeof(float2);
     const size_t bytes_g = (size_t)nproj * n * FZ * sizeof(float2);
-    const size_t bytes_f = (size_t)two_n * two_n * FZ * sizeof(float2);
+    const size_t bytes_f = (size_t)two_n * two_n * zc_max * sizeof(float2);
     const size_t bytes_tab = ((size_t)nh * sizeof(float2) + (size_t)nproj * 4 * sizeof(float) + (size_t)nproj * sizeof(int) + 1024);
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     char *ws = nullptr;
@@ -366,11 +361,6 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
         TOMO_HIPG(hipMemcpyAsync(order, h_order.data(), nproj * sizeof(int), hipMemcpyHostToDevice, st));
         TOMO_HIPG(hipStreamSynchronize(st));  // host vectors go out of scope at the end of this block only; be explicit
 
-        {   // 2D inverse plan on the z-fastest layout
-            int dims[2] = {two_n, two_n};
-            TOMO_FFT(hipfftPlanMany(&p_2d, 2, dims, dims, FZ, 1, dims, FZ, 1, HIPFFT_C2C, FZ));
-            TOMO_FFT(hipfftSetStream(p_2d, st));
-        }
         const int pad_m = ne / 2 - raw_n / 2, crop_m = ne / 2 - n / 2;
         const float phi_scale = (float)(1 - n % 4) / (float)nproj;
         for (int c0 = 0; c0 < nzh; c0 += FZ) {
@@ -399,9 +389,13 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
             // ---- STEP 1: 1D FFT along the detector (methodsDIR_CuPy.py:723-724)
             if (zc != zc_planned) {
                 if (p_c2c) { (void)hipfftDestroy(p_c2c); p_c2c = 0; }
+                if (p_2d) { (void)hipfftDestroy(p_2d); p_2d = 0; }
                 int len[1] = {n};
                 TOMO_FFT(hipfftPlanMany(&p_c2c, 1, len, nullptr, 1, n, nullptr, 1, n, HIPFFT_C2C, zc * nproj));
                 TOMO_FFT(hipfftSetStream(p_c2c, st));
+                int dims[2] = {two_n, two_n};
+                TOMO_FFT(hipfftPlanMany(&p_2d, 2, dims, nullptr, 1, two_n * two_n, nullptr, 1, two_n * two_n, HIPFFT_C2C, zc));
+                TOMO_FFT(hipfftSetStream(p_2d, st));
                 zc_planned = zc;
             }
             TOMO_FFT(hipfftExecC2C(p_c2c, (hipfftComplex *)datac, (hipfftComplex *)datac, HIPFFT_FORWARD));
@@ -417,14 +411,14 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
                 ga.center_size = center_size;
                 ga.use_center = center_size >= 192 ? 1 : 0;  // _CENTER_SIZE_MIN, methodsDIR_CuPy.py:23
                 dim3 grid(ceil_div(two_n, 4 * GP), two_n);
-                gather_kernel<<<grid, 256, 0, st>>>(ga);
+                gather_kernel<<<grid, 256, 0, st>>>(ga, zc);
             }
             // ---- STEP 3: 2D inverse FFT (methodsDIR_CuPy.py:851-897); the shifts live in the neighbouring kernels
             TOMO_FFT(hipfftExecC2C(p_2d, (hipfftComplex *)f, (hipfftComplex *)f, HIPFFT_BACKWARD));
             // ---- STEP 4: unpadding x phi (methodsDIR_CuPy.py:920-967)
             {
-                dim3 grid(ceil_div(out_size, 32), out_size);
-                unpad_kernel<<<grid, 256, 0, st>>>(f, out_dev, n, unpad_m, out_size, zc, 2 * c0, out_z, mu, phi_scale,
+                dim3 grid(ceil_div(out_size, 256), out_size, zc);
+                unpad_kernel<<<grid, 256, 0, st>>>(f, out_dev, n, unpad_m, out_size, 2 * c0, out_z, mu, phi_scale,
                                                    1.0f / ((float)two_n * (float)two_n));
             }
             TOMO_HIPG(hipGetLastError());

@@ -200,7 +200,7 @@ class RecToolsDIRCuPy:
             rows_sub = max(1, min(2 * zc * nproj, (64 << 20) // ne))
             sizes = [int(np.prod(shape)) * itemsize, nz_even * nproj * raw_n * 4 if (odd_horiz or odd_vert) else 0,
                      rows_sub * ne * 4, rows_sub * (ne // 2 + 1) * 8, zc * nproj * n * 8, nproj * n * 64 * 8,
-                     (2 * n) * (2 * n) * 64 * 8, int(np.prod(out_shape)) * 4]
+                     (2 * n) * (2 * n) * zc * 8, int(np.prod(out_shape)) * 4]
             for b in sizes:
                 if b:
                     mem_stack.malloc(b)
