@@ -233,7 +233,8 @@ int tomo_fbp_filter(int device, float *data_dev, size_t rows, int nu, float cuto
  *   m, mu     footprint half-width and Gaussian parameter (:321-322, :726-737)
  *   center_size  min(center_size, 2n) of the reference (:290): >= 192 selects the circular-support gathering inside
  *             the centre box and the square-footprint form outside it; < 192 the square-footprint form everywhere.
- * Allocates its workspace per call, processes 128 slices per chunk, synchronises the stream before returning. */
+ * Workspace: the per-device scratch arena; hipFFT plans are cached between calls (both released by
+ * tomo_release_scratch).  Processes 128 slices per chunk, synchronises the stream before returning. */
 int tomo_fourier_inv(int device, const float *data_dev, float *out_dev, int nz, int out_z, int nproj, int raw_n,
                      int n, int ne, int unpad_m, int out_size, const float *w_host, const float *theta_host,
                      int m, float mu, int center_size, void *stream);

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -41,6 +42,41 @@ namespace {
     } while (0)
 
 constexpr int FZ = 64;  // slice pairs per chunk = lanes of a wave
+
+// hipFFT plans are kept between calls (creation runs the library's run-time kernel generation and allocates work areas:
+// tens of milliseconds per call otherwise).  Released together with the scratch arena (tomo_release_scratch).
+struct PlanKey {
+    int device, kind, len, batch;
+    bool operator==(const PlanKey &o) const { return device == o.device && kind == o.kind && len == o.len && batch == o.batch; }
+};
+struct PlanEntry { PlanKey key; hipfftHandle h; };
+std::mutex g_plan_mu;
+std::vector<PlanEntry> g_plans;
+enum { PLAN_R2C = 0, PLAN_C2R = 1, PLAN_C2C_1D = 2, PLAN_C2C_2D = 3 };
+
+int get_plan(int device, int kind, int len, int batch, hipStream_t st, hipfftHandle *out)
+{
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    const PlanKey key{device, kind, len, batch};
+    for (auto &e : g_plans)
+        if (e.key == key) {
+            if (hipfftSetStream(e.h, st) != HIPFFT_SUCCESS) return tomo_fail(TOMO_E_RUNTIME, "hipfftSetStream failed");
+            *out = e.h;
+            return TOMO_OK;
+        }
+    hipfftHandle h = 0;
+    int dims[2] = {len, len};
+    hipfftResult r;
+    if (kind == PLAN_R2C) r = hipfftPlanMany(&h, 1, dims, nullptr, 1, len, nullptr, 1, len / 2 + 1, HIPFFT_R2C, batch);
+    else if (kind == PLAN_C2R) r = hipfftPlanMany(&h, 1, dims, nullptr, 1, len / 2 + 1, nullptr, 1, len, HIPFFT_C2R, batch);
+    else if (kind == PLAN_C2C_1D) r = hipfftPlanMany(&h, 1, dims, nullptr, 1, len, nullptr, 1, len, HIPFFT_C2C, batch);
+    else r = hipfftPlanMany(&h, 2, dims, nullptr, 1, len * len, nullptr, 1, len * len, HIPFFT_C2C, batch);
+    if (r != HIPFFT_SUCCESS) return tomo_fail(TOMO_E_RUNTIME, "hipfftPlanMany(kind %d, len %d, batch %d) failed: %d", kind, len, batch, (int)r);
+    if (hipfftSetStream(h, st) != HIPFFT_SUCCESS) { (void)hipfftDestroy(h); return tomo_fail(TOMO_E_RUNTIME, "hipfftSetStream failed"); }
+    g_plans.push_back(PlanEntry{key, h});
+    *out = h;
+    return TOMO_OK;
+}
 constexpr float PI_F = 3.1415926535897932384626433832795f;  // fft_us_kernels.cu:2
 
 // ---- filter stage -------------------------------------------------------------------------------------------------
@@ -142,46 +178,68 @@ __device__ __forceinline__ void gather_center_point(const GatherArgs &a, int tx,
     const float px = (float)(tx - n) / (float)(2 * n), py = (float)(n - ty) / (float)(2 * n);
     const float rho2 = px * px + py * py;
 
-    auto one_angle = [&](int pi) {
-        const float costheta = a.ct[pi], sintheta = a.st[pi];
-        const float vx = 0.5f * costheta, vy = 0.5f * sintheta;
-        const float dot = vx * px + vy * py;
-        const float mx = dot * vx / 0.25f, my = dot * vy / 0.25f;
-        const float d2 = (mx - px) * (mx - px) + (my - py) * (my - py);
-        if (!(radius_2 >= d2)) return;
-        const float dti = sqrtf(radius_2 - d2);
-        int rmin, rmax;
-        if (fabsf(vx) > fabsf(vy)) {
-            rmin = n / 2 - 1 + (int)floorf((mx - dti * vx / 0.5f) / (2.0f * vx / (float)n));
-            rmax = n / 2 + 1 + (int)floorf((mx + dti * vx / 0.5f) / (2.0f * vx / (float)n));
-        } else {
-            rmin = n / 2 - 1 + (int)floorf((my - dti * vy / 0.5f) / (2.0f * vy / (float)n));
-            rmax = n / 2 + 1 + (int)floorf((my + dti * vy / 0.5f) / (2.0f * vy / (float)n));
-        }
-        if (rmin > rmax) { const int t = rmax; rmax = rmin; rmin = t; }
-        rmin = min(max(rmin, 0), n - 1);
-        rmax = min(max(rmax, 0), n - 1);
-        const float2 *row = a.g + ((size_t)pi * n) * FZ + lane;
-        for (int ri = rmin; ri < rmax; ++ri) {
-            const float rr = (float)(ri - n / 2) / (float)n;
-            const float x0 = clamp_half(rr * costheta), y0 = clamp_half(rr * sintheta);
-            const float w0 = px - x0, w1 = py - y0;
-            const float w = coeff0 * __expf(coeff1 * (w0 * w0 + w1 * w1));
-            const float2 v = row[(size_t)ri * FZ];
-            acc.x += v.x * w;
-            acc.y += v.y * w;
+    // Sorted angles [k0, k1): the per-ray geometry (distance test, radial range) is evaluated LANE-PARALLEL, one
+    // candidate ray per lane; the rays that pass are then visited in ascending order (the reference's summation order),
+    // their Gaussian weights again lane-parallel (one radial sample per lane, a ray has < 64 of them), and only the
+    // final multiply-accumulate over the 64 slice pairs runs once per sample: weight from a v_readlane, one 512-byte row.
+    auto angle_range = [&](int k0, int k1) {
+        for (int kb = k0; kb < k1; kb += 64) {
+            const int k = kb + lane;
+            const int pi = a.order[min(k, k1 - 1)];
+            const float costheta = a.ct[pi], sintheta = a.st[pi];
+            const float vx = 0.5f * costheta, vy = 0.5f * sintheta;
+            const float dot = vx * px + vy * py;
+            const float mx = dot * vx / 0.25f, my = dot * vy / 0.25f;
+            const float d2 = (mx - px) * (mx - px) + (my - py) * (my - py);
+            const bool hit = (k < k1) && (radius_2 >= d2);
+            const float dti = sqrtf(fmaxf(radius_2 - d2, 0.0f));
+            int rmin, rmax;
+            if (fabsf(vx) > fabsf(vy)) {
+                rmin = n / 2 - 1 + (int)floorf((mx - dti * vx / 0.5f) / (2.0f * vx / (float)n));
+                rmax = n / 2 + 1 + (int)floorf((mx + dti * vx / 0.5f) / (2.0f * vx / (float)n));
+            } else {
+                rmin = n / 2 - 1 + (int)floorf((my - dti * vy / 0.5f) / (2.0f * vy / (float)n));
+                rmax = n / 2 + 1 + (int)floorf((my + dti * vy / 0.5f) / (2.0f * vy / (float)n));
+            }
+            if (rmin > rmax) { const int t = rmax; rmax = rmin; rmin = t; }
+            rmin = min(max(rmin, 0), n - 1);
+            rmax = min(max(rmax, 0), n - 1);
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
+            while (todo) {
+                const int l = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int pi_l = __builtin_amdgcn_readlane(pi, l);
+                const int r0 = __builtin_amdgcn_readlane(rmin, l), r1 = __builtin_amdgcn_readlane(rmax, l);
+                const float c_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(costheta), l));
+                const float s_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sintheta), l));
+                const float2 *row = a.g + ((size_t)pi_l * n) * FZ + lane;
+                for (int rb = r0; rb < r1; rb += 64) {  // one radial sample per lane (a ray has ~10; the loop is for safety)
+                    const int ri = rb + lane;
+                    const float rr = (float)(ri - n / 2) / (float)n;
+                    const float x0 = clamp_half(rr * c_l), y0 = clamp_half(rr * s_l);
+                    const float w0 = px - x0, w1 = py - y0;
+                    const float w = coeff0 * __expf(coeff1 * (w0 * w0 + w1 * w1));
+                    const int cnt = min(64, r1 - rb);
+                    for (int j = 0; j < cnt; ++j) {
+                        const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), j));
+                        const float2 v = row[(size_t)(rb + j) * FZ];
+                        acc.x += v.x * wj;
+                        acc.y += v.y * wj;
+                    }
+                }
+            }
         }
     };
 
     if (radius_2 >= rho2) {  // every ray passes within the support radius
-        for (int k = 0; k < a.nproj; ++k) one_angle(a.order[k]);
+        angle_range(0, a.nproj);
         return;
     }
-    // rays within asin(R / rho) of the direction of the point, modulo pi; a small margin, the exact test is in one_angle
+    // rays within asin(R / rho) of the direction of the point, modulo pi; a small margin, the exact test is in angle_range
     const float rho = sqrtf(rho2);
     const float delta = asinf(fminf(sqrtf(radius_2) / rho, 1.0f)) + 2.0e-3f;
     if (2.0f * delta >= PI_F) {
-        for (int k = 0; k < a.nproj; ++k) one_angle(a.order[k]);
+        angle_range(0, a.nproj);
         return;
     }
     const float phi = atan2f(py, px);
@@ -192,9 +250,9 @@ __device__ __forceinline__ void gather_center_point(const GatherArgs &a, int tx,
     for (;; ++j) {
         const float c = phi + (float)j * PI_F;
         if (c - delta > tmax) break;
-        int k0 = max(lower_bound_f(a.sth, a.nproj, c - delta), done_until);
+        const int k0 = max(lower_bound_f(a.sth, a.nproj, c - delta), done_until);
         const int k1 = lower_bound_f(a.sth, a.nproj, c + delta);  // exclusive
-        for (int k = k0; k < k1; ++k) one_angle(a.order[k]);
+        if (k1 > k0) angle_range(k0, k1);
         done_until = max(done_until, k1);
     }
 }
@@ -300,6 +358,19 @@ __global__ __launch_bounds__(256) void unpad_kernel(const float2 *__restrict__ f
 
 }  // namespace
 
+void tomo_fourier_cache_release(int device)
+{
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    for (size_t i = 0; i < g_plans.size();) {
+        if (g_plans[i].key.device == device) {
+            (void)hipfftDestroy(g_plans[i].h);
+            g_plans.erase(g_plans.begin() + (long)i);
+        } else {
+            ++i;
+        }
+    }
+}
+
 extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_dev, int nz, int out_z, int nproj, int raw_n,
                                 int n, int ne, int unpad_m, int out_size, const float *w_host, const float *theta_host,
                                 int m, float mu, int center_size, void *stream)
@@ -329,12 +400,12 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     char *ws = nullptr;
     hipfftHandle p_r2c = 0, p_c2r = 0, p_c2c = 0, p_2d = 0;
-    size_t rows_planned = 0;
-    int zc_planned = 0;
-    {
+    {   // workspace: the per-device grow-only scratch arena (shared with the TV operators, released by tomo_release_scratch)
         const size_t total = al(bytes_buf) + al(bytes_spec) + al(bytes_datac) + al(bytes_g) + al(bytes_f) + al(bytes_tab);
-        hipError_t e = hipMalloc((void **)&ws, total);
-        if (e != hipSuccess) return tomo_fail(TOMO_E_NOMEM, "Fourier reconstruction workspace of %zu bytes: %s", total, hipGetErrorString(e));
+        void *base = nullptr;
+        rc = tomo_arena_get(device, total, &base);
+        if (rc != TOMO_OK) return rc;
+        ws = (char *)base;
     }
     {
         float *buf = (float *)ws;
@@ -369,16 +440,8 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
             // ---- STEP 0: filter (methodsDIR_CuPy.py:449-545), output paired + shifted into datac[z][p][x]
             for (size_t r0 = 0; r0 < rows; r0 += rows_sub) {
                 const size_t rs = std::min(rows_sub, rows - r0);
-                if (rs != rows_planned) {
-                    if (p_r2c) { (void)hipfftDestroy(p_r2c); p_r2c = 0; }
-                    if (p_c2r) { (void)hipfftDestroy(p_c2r); p_c2r = 0; }
-                    int len[1] = {ne};
-                    TOMO_FFT(hipfftPlanMany(&p_r2c, 1, len, nullptr, 1, ne, nullptr, 1, nh, HIPFFT_R2C, (int)rs));
-                    TOMO_FFT(hipfftPlanMany(&p_c2r, 1, len, nullptr, 1, nh, nullptr, 1, ne, HIPFFT_C2R, (int)rs));
-                    TOMO_FFT(hipfftSetStream(p_r2c, st));
-                    TOMO_FFT(hipfftSetStream(p_c2r, st));
-                    rows_planned = rs;
-                }
+                if ((rc = get_plan(device, PLAN_R2C, ne, (int)rs, st, &p_r2c)) != TOMO_OK) goto done;
+                if ((rc = get_plan(device, PLAN_C2R, ne, (int)rs, st, &p_c2r)) != TOMO_OK) goto done;
                 const float *src = data_dev + ((size_t)2 * c0 * nproj + r0) * raw_n;
                 pad_edge_kernel<<<2048, 256, 0, st>>>(src, buf, rs, raw_n, ne, pad_m);
                 TOMO_FFT(hipfftExecR2C(p_r2c, buf, (hipfftComplex *)spec));
@@ -387,17 +450,8 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
                 crop_pair_kernel<<<2048, 256, 0, st>>>(buf, datac, rs, r0, nproj, n, ne, crop_m, 1.0f / (float)ne);
             }
             // ---- STEP 1: 1D FFT along the detector (methodsDIR_CuPy.py:723-724)
-            if (zc != zc_planned) {
-                if (p_c2c) { (void)hipfftDestroy(p_c2c); p_c2c = 0; }
-                if (p_2d) { (void)hipfftDestroy(p_2d); p_2d = 0; }
-                int len[1] = {n};
-                TOMO_FFT(hipfftPlanMany(&p_c2c, 1, len, nullptr, 1, n, nullptr, 1, n, HIPFFT_C2C, zc * nproj));
-                TOMO_FFT(hipfftSetStream(p_c2c, st));
-                int dims[2] = {two_n, two_n};
-                TOMO_FFT(hipfftPlanMany(&p_2d, 2, dims, nullptr, 1, two_n * two_n, nullptr, 1, two_n * two_n, HIPFFT_C2C, zc));
-                TOMO_FFT(hipfftSetStream(p_2d, st));
-                zc_planned = zc;
-            }
+            if ((rc = get_plan(device, PLAN_C2C_1D, n, zc * nproj, st, &p_c2c)) != TOMO_OK) goto done;
+            if ((rc = get_plan(device, PLAN_C2C_2D, two_n, zc, st, &p_2d)) != TOMO_OK) goto done;
             TOMO_FFT(hipfftExecC2C(p_c2c, (hipfftComplex *)datac, (hipfftComplex *)datac, HIPFFT_FORWARD));
             {
                 dim3 grid(ceil_div(n, 64), nproj);
@@ -423,13 +477,9 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
             }
             TOMO_HIPG(hipGetLastError());
         }
-        TOMO_HIPG(hipStreamSynchronize(st));  // the workspace and the plans are released below
+        TOMO_HIPG(hipStreamSynchronize(st));  // the arena may be handed to another operator as soon as we return
     }
 done:
-    if (p_r2c) (void)hipfftDestroy(p_r2c);
-    if (p_c2r) (void)hipfftDestroy(p_c2r);
-    if (p_c2c) (void)hipfftDestroy(p_c2c);
-    if (p_2d) (void)hipfftDestroy(p_2d);
-    if (ws) { (void)hipStreamSynchronize(st); (void)hipFree(ws); }
+    if (rc != TOMO_OK) (void)hipStreamSynchronize(st);
     return rc;
 }

@@ -246,6 +246,7 @@ int tomo_arena_get(int device, size_t bytes, void **out)
 
 extern "C" int tomo_release_scratch(int device)
 {
+    tomo_fourier_cache_release(device);
     std::lock_guard<std::mutex> lk(g_arena_mu);
     auto it = g_arenas.find(device);
     if (it != g_arenas.end() && it->second.ptr) {

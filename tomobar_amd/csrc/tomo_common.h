@@ -66,6 +66,7 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 
 // grow-only per-device arena used by the TV drivers (tomo_release_scratch frees it)
 int tomo_arena_get(int device, size_t bytes, void **out);
+void tomo_fourier_cache_release(int device);  // cached hipFFT plans of fourier_inv.hip
 
 // kernel-variant switches (tomo_set_variant)
 extern int g_variant_bp, g_variant_fp, g_variant_pdtv, g_variant_roftv;
