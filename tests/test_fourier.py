@@ -81,6 +81,18 @@ def test_product_filter_tables_vs_oracle(FO):
         FT.calc_filter(128, "boxcar", 1.0)
 
 
+@pytest.mark.parametrize("name,median", [("none", 100), ("ramp", 0.496701), ("shepp", 0.447188), ("cosine", 0.25168),
+                                         ("cosine2", 0.164889), ("hamming", 0.185245), ("hann", 0.164889),
+                                         ("parzen", 0.042508)])
+def test_calc_filter_known_answers_of_the_reference(FO, name, median):
+    """the data-free literals of the reference's own test (tests/test_fourier.py:5-27): median of calc_filter(100, ., 1.0)"""
+    from tomobar_amd import fourier as FT
+    for impl in (FO.calc_filter, FT.calc_filter):
+        f = np.sort(impl(100, name, 1.0))
+        assert f.size == 51
+        np.testing.assert_allclose(f[f.size // 2], median, rtol=1e-5)
+
+
 def test_memory_estimator_dry_run_needs_no_gpu():
     from tomobar_amd.supp.memory_estimator_helpers import DeviceMemStack
     st = DeviceMemStack()
