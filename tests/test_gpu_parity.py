@@ -314,3 +314,66 @@ def test_pad_crop_mask_permute(oracle, ops):
     t = dev(rng.random((4, 5, 6)).astype(np.float32))
     for perm in ((1, 0, 2), (2, 1, 0), (0, 2, 1), (2, 0, 1)):
         assert np.array_equal(host(ops.contiguous(t.permute(*perm))), np.ascontiguousarray(host(t).transpose(perm)))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_projector_pair_random_geometries(oracle, ops, seed):
+    """seeded random geometries (sizes that are not multiples of any tile, detector wider / narrower than the grid,
+    large rotation-axis offsets, arbitrary angle ranges incl. > 360 degrees and descending order, subsets with ragged
+    tails): FP and BP of every kernel variant against the oracle, bit for bit"""
+    from tomobar_amd.projector import HipTools3D
+    rng = np.random.default_rng(1000 + seed)
+    nz = int(rng.integers(1, 40))
+    n = int(rng.integers(3, 150))
+    nu = int(max(2, n + rng.integers(-n // 2, n // 2 + 1)))
+    na = int(rng.integers(1, 70))
+    start = float(rng.uniform(-np.pi, np.pi))
+    span = float(rng.choice([np.pi, 2 * np.pi, 0.3, 7.5])) * float(rng.choice([1.0, -1.0]))
+    angles = start + np.linspace(0, span, na, endpoint=False)
+    cor = float(rng.uniform(-0.2, 0.2) * nu) if seed % 3 else np.asarray(rng.uniform(-3, 3, na))
+    os_n = int(rng.integers(1, min(na, 9) + 1))
+    P = oracle.Projector(nz, n, nu, angles, cor, os_n)
+    H = HipTools3D(nu, 0, nz, angles, cor, n, "gpu", 0, os_n if os_n > 1 else None)
+    vol = rng.standard_normal((nz, n, n)).astype(np.float32)
+    subsets = [None] if os_n == 1 else list(range(os_n))
+    for s in subsets:
+        nsel = len(P.subsets[s]) if s is not None else na
+        if nsel == 0:  # the reference's one-element trim can empty a subset (OS_number == angles): nothing to project
+            continue
+        sino = rng.standard_normal((nz, nsel, nu)).astype(np.float32)
+        want_fp, want_bp = P.fp(vol, s), P.bp(sino, s)
+        for v in (0, 2, 1):
+            ops.set_variant("fp", v)
+            got = host(H.forward(dev(vol), s))
+            assert np.array_equal(got, want_fp), ("fp", v, seed, s, (nz, n, nu, na, os_n))
+        ops.set_variant("fp", 0)
+        for v in (0, 2, 1):
+            ops.set_variant("bp", v)
+            got = host(H.backward(dev(sino), s))
+            assert np.array_equal(got, want_bp), ("bp", v, seed, s, (nz, n, nu, na, os_n))
+        ops.set_variant("bp", 0)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_tv_random_shapes(oracle, ops, seed):
+    """seeded random 2D/3D shapes (straddling the 60/62-lane segments, the 4/8-row blocks and the z-chunk boundaries of
+    the z-march kernels), random iteration counts (odd counts end with the single-iteration kernel), every option:
+    default PD_TV / ROF_TV kernels against the oracle, bit for bit"""
+    from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
+    rng = np.random.default_rng(2000 + seed)
+    if seed % 4 == 0:
+        shape = (int(rng.integers(2, 200)), int(rng.integers(2, 260)))
+    else:
+        shape = (int(rng.integers(2, 120)), int(rng.integers(2, 70)), int(rng.integers(2, 200)))
+    x = (rng.random(shape) * 0.4 + (np.indices(shape)[-1] > shape[-1] // 3) - 0.3).astype(np.float32)
+    iters = int(rng.integers(1, 9))
+    half, mtv, nn = bool(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    lam = float(rng.choice([0.01, 0.05, 0.3]))
+    ops.set_variant("pdtv", 0)
+    ops.set_variant("roftv", 0)
+    want = oracle.pd_tv(x, lam, iters, mtv, nn, 8.0, half)
+    got = host(PD_TV_cupy(dev(x), lam, iters, mtv, nn, 8.0, 0, half))
+    assert np.array_equal(got, want), ("pd", shape, iters, half, mtv, nn, np.abs(got - want).max())
+    want = oracle.rof_tv(x, lam, iters, 0.004, half)
+    got = host(ROF_TV_cupy(dev(x), lam, iters, 0.004, 0, half))
+    assert np.array_equal(got, want), ("rof", shape, iters, half, np.abs(got - want).max())

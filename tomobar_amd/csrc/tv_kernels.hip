@@ -4,14 +4,16 @@
 //   tomobar/cuda_kernels/primal_dual_for_total_variation.cu:125-261 (3D), :360-452 (2D)
 //   tomobar/cuda_kernels/rudin_osher_fatemi_total_variation.cu:66-137 (2D), :156-238 (3D)
 // How it is computed here is MI355X-first:
-//   * PD_TV variant 0 ("zmarch"): every 64-lane wave is autonomous.  A lane owns RY consecutive rows of one
-//     x column and marches along z.  +-y neighbours are other registers of the same lane, +-x neighbours come
-//     from wave shuffles, the z-1 dual is carried in registers from the previous step, so each U / P / Input
-//     value is read from HBM once per iteration (plus a one-row / one-lane halo served by L2) and no LDS or
-//     barrier is used.  Lane 0 of every wave is an x-halo lane (63 outputs per wave).
-//   * variant 1 ("pervoxel"): one thread per voxel, neighbours' duals recomputed from global memory; kept as
-//     an independent implementation for A/B checks.
-//   * ROF_TV: divergence and update kernels fused: the D fields never reach HBM (12 B/voxel/iteration).
+//   * PD_TV default: pd_zmarch_x2.inl, TWO iterations per pass through HBM.  A lane owns 4 consecutive rows of one
+//     x column and marches along z; +-y neighbours are other registers of the same lane, +-x neighbours come from
+//     DPP wave shifts (2 halo lanes either side), the z-1 duals are carried in registers, iteration n+1 -> n+2 runs
+//     one plane behind iteration n -> n+1 in the same wave.  2 x 2 waves per workgroup walk z in lockstep so that
+//     the lines they share merge in L1.  Odd iteration counts / the single-step slab entry use pd_zmarch2.inl (one
+//     iteration, 8 rows per lane).  Measured history and PMC evidence: DESIGN.md sections 4 and 6.
+//   * variant 1 ("pervoxel"): one thread per voxel, neighbours' duals recomputed from global memory; variant 2: the
+//     first, unsynchronised z-march (63 outputs per wave).  Both kept as independent implementations for A/B checks.
+//   * ROF_TV: rof_zmarch.inl, divergence and update fused on the same z-march skeleton: the D fields never reach
+//     HBM (12 B/voxel/iteration) and are evaluated once per voxel.  Variant 1: per-voxel form.
 // All arithmetic is float32 with the rounding sequence of oracle/tomo_oracle.c (explicit fmaf, -ffp-contract=off).
 #include "tomo_common.h"
 
