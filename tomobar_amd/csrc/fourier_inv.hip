@@ -11,7 +11,8 @@
 //     g[angle][radius][z] 64 slice pairs (128 slices) per chunk.  A wave owns one
 //     grid point at a time with one lane per slice pair: the geometry of the gathering (which angles pass within the
 //     support radius, which radial samples, the Gaussian weights -- the reference recomputes all of it per slice) is
-//     wave-uniform and computed once for 64 slice pairs, every sample fetch is one coalesced 512-byte row, and the sum
+//     wave-uniform and computed once for 64 slice pairs (lane-parallel over candidate rays / radial samples), every
+//     sample fetch is one coalesced 512-byte row shared by the 8 grid points of the wave, and the sum
 //     runs in the reference's order (angles ascending, radius ascending), so the result is deterministic (the reference's
 //     small-detector path accumulates with atomics);
 //   * a wave leaves its 16 grid points x 64 slice pairs through an LDS transpose, as 128-byte lines of f[z][ky][kx], so
@@ -257,6 +258,128 @@ __device__ __forceinline__ void gather_center_point(const GatherArgs &a, int tx,
     }
 }
 
+// The same for the GPB consecutive grid points (tx0 .. tx0+GPB-1, ty) of a wave at once.  Neighbouring points draw on
+// nearly the same samples: the per-point form re-reads every 512-byte sample row once per point (PMC: 80 % L1 hits but
+// 216 GB of L2 traffic per 128-slice chunk at 2048 x 1800, waves waiting 75 % of the time).  Here a ray's rows are read
+// once for the union of the points' radial ranges and multiplied into GPB accumulators with per-point weights (zero
+// outside a point's own range: adds exactly nothing, the per-point order angle-ascending / radius-ascending is kept).
+// ``pmask`` bit q = point q takes part (inside the grid and the centre box).
+constexpr int GPB = 8;
+
+__device__ __forceinline__ void gather_center_block(const GatherArgs &a, int tx0, int ty, unsigned pmask, int lane, float2 (&acc)[GPB])
+{
+    const int n = a.n;
+    const float coeff0 = PI_F / a.mu, coeff1 = -PI_F * PI_F / a.mu;
+    const float fs2 = (float)(4 * n) * (float)n;
+    const float radius_2 = 2.0f * ((float)a.m + 0.5f) * ((float)a.m + 0.5f) / fs2;
+    const float py = (float)(n - ty) / (float)(2 * n);
+    float pxq[GPB];
+#pragma unroll
+    for (int q = 0; q < GPB; ++q) pxq[q] = (float)(tx0 + q - n) / (float)(2 * n);
+
+    auto angle_range = [&](int k0, int k1) {
+        for (int kb = k0; kb < k1; kb += 64) {
+            const int k = kb + lane;
+            const int pi = a.order[min(k, k1 - 1)];
+            const float costheta = a.ct[pi], sintheta = a.st[pi];
+            const float vx = 0.5f * costheta, vy = 0.5f * sintheta;
+            const bool xdom = fabsf(vx) > fabsf(vy);
+            int lo_hi[GPB];          // rmin | rmax << 16 per point (n <= 16384)
+            unsigned hits = 0;
+            int umin = n, umax = 0;
+#pragma unroll
+            for (int q = 0; q < GPB; ++q) {
+                const float px = pxq[q];
+                const float dot = vx * px + vy * py;
+                const float mx = dot * vx / 0.25f, my = dot * vy / 0.25f;
+                const float d2 = (mx - px) * (mx - px) + (my - py) * (my - py);
+                const bool hit = (k < k1) && ((pmask >> q) & 1u) && (radius_2 >= d2);
+                const float dti = sqrtf(fmaxf(radius_2 - d2, 0.0f));
+                int rmin, rmax;
+                if (xdom) {
+                    rmin = n / 2 - 1 + (int)floorf((mx - dti * vx / 0.5f) / (2.0f * vx / (float)n));
+                    rmax = n / 2 + 1 + (int)floorf((mx + dti * vx / 0.5f) / (2.0f * vx / (float)n));
+                } else {
+                    rmin = n / 2 - 1 + (int)floorf((my - dti * vy / 0.5f) / (2.0f * vy / (float)n));
+                    rmax = n / 2 + 1 + (int)floorf((my + dti * vy / 0.5f) / (2.0f * vy / (float)n));
+                }
+                if (rmin > rmax) { const int t = rmax; rmax = rmin; rmin = t; }
+                rmin = min(max(rmin, 0), n - 1);
+                rmax = min(max(rmax, 0), n - 1);
+                if (!hit) rmax = rmin;  // empty range
+                lo_hi[q] = rmin | (rmax << 16);
+                if (hit && rmax > rmin) {
+                    hits |= 1u << q;
+                    umin = min(umin, rmin);
+                    umax = max(umax, rmax);
+                }
+            }
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(hits != 0);
+            while (todo) {
+                const int l = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int pi_l = __builtin_amdgcn_readlane(pi, l);
+                const int u0 = __builtin_amdgcn_readlane(umin, l), u1 = __builtin_amdgcn_readlane(umax, l);
+                const float c_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(costheta), l));
+                const float s_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sintheta), l));
+                int r_q[GPB];
+#pragma unroll
+                for (int q = 0; q < GPB; ++q) r_q[q] = __builtin_amdgcn_readlane(lo_hi[q], l);
+                const float2 *row = a.g + ((size_t)pi_l * n) * FZ + lane;
+                for (int rb = u0; rb < u1; rb += 64) {  // one radial sample per lane (the union has ~20)
+                    const int ri = rb + lane;
+                    const float rr = (float)(ri - n / 2) / (float)n;
+                    const float x0 = clamp_half(rr * c_l), y0 = clamp_half(rr * s_l);
+                    const float w1 = py - y0;
+                    float w[GPB];
+#pragma unroll
+                    for (int q = 0; q < GPB; ++q) {
+                        const float w0 = pxq[q] - x0;
+                        const float wv = coeff0 * __expf(coeff1 * (w0 * w0 + w1 * w1));
+                        w[q] = (ri >= (r_q[q] & 0xffff) && ri < (r_q[q] >> 16)) ? wv : 0.0f;
+                    }
+                    const int cnt = min(64, u1 - rb);
+                    for (int j = 0; j < cnt; ++j) {
+                        const float2 v = row[(size_t)(rb + j) * FZ];
+#pragma unroll
+                        for (int q = 0; q < GPB; ++q) {
+                            const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[q]), j));
+                            acc[q].x += v.x * wj;
+                            acc[q].y += v.y * wj;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    // angular pruning for the whole block: a circle around its middle that contains every point's support circle
+    const float pxc = 0.5f * (pxq[0] + pxq[GPB - 1]);
+    const float rho = sqrtf(pxc * pxc + py * py);
+    const float rblk = sqrtf(radius_2) + (float)(GPB / 2 + 1) / (float)(2 * n);
+    if (rblk >= rho) {
+        angle_range(0, a.nproj);
+        return;
+    }
+    const float delta = asinf(fminf(rblk / rho, 1.0f)) + 2.0e-3f;
+    if (2.0f * delta >= PI_F) {
+        angle_range(0, a.nproj);
+        return;
+    }
+    const float phi = atan2f(py, pxc);
+    const float tmin = a.sth[0], tmax = a.sth[a.nproj - 1];
+    int j = (int)ceilf((tmin - delta - phi) / PI_F);
+    int done_until = 0;
+    for (;; ++j) {
+        const float c = phi + (float)j * PI_F;
+        if (c - delta > tmax) break;
+        const int k0 = max(lower_bound_f(a.sth, a.nproj, c - delta), done_until);
+        const int k1 = lower_bound_f(a.sth, a.nproj, c + delta);  // exclusive
+        if (k1 > k0) angle_range(k0, k1);
+        done_until = max(done_until, k1);
+    }
+}
+
 // One grid point in the reference's scatter form seen from the receiving side (gather_kernel / gather_kernel_partial,
 // fft_us_kernels.cu:5-113): a sample contributes when the point lies in its (2m+1)^2 footprint (periodic wrap).
 __device__ __forceinline__ void gather_square_point(const GatherArgs &a, int ix, int iy, int lane, float2 &acc)
@@ -314,17 +437,24 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs a, int zc)
     const int iy = blockIdx.y;
     const int x_first = (blockIdx.x * 4 + wave) * GP;
     const int chs = a.center_size / 2, base = max(0, a.n - chs);
-    for (int q = 0; q < GP; ++q) {
+    static_assert(GP == GPB, "one block of points per wave");
+    float2 accs[GPB];
+    unsigned cmask = 0;  // points gathered in the centre form
+#pragma unroll
+    for (int q = 0; q < GPB; ++q) {
+        accs[q] = make_float2(0.0f, 0.0f);
         const int ix = x_first + q;
-        float2 acc = make_float2(0.0f, 0.0f);
-        if (ix < two_n) {
-            const bool in_box = a.use_center && ix >= base && ix < base + a.center_size && iy >= base && iy < base + a.center_size;
-            if (in_box) gather_center_point(a, ix, iy, lane, acc);
-            else gather_square_point(a, ix, iy, lane, acc);
-        }
+        const bool in_box = a.use_center && ix < two_n && ix >= base && ix < base + a.center_size && iy >= base && iy < base + a.center_size;
+        if (in_box) cmask |= 1u << q;
+    }
+    if (cmask) gather_center_block(a, x_first, iy, cmask, lane, accs);
+#pragma unroll
+    for (int q = 0; q < GPB; ++q) {
+        const int ix = x_first + q;
+        if (!((cmask >> q) & 1u) && ix < two_n) gather_square_point(a, ix, iy, lane, accs[q]);
         // first c2dfftshift (fft_us_kernels.cu:579-603) folded into the store
         const float chk = ((ix ^ iy) & 1) ? -1.0f : 1.0f;
-        stage[wave][q][lane] = make_float2(acc.x * chk, acc.y * chk);
+        stage[wave][q][lane] = make_float2(accs[q].x * chk, accs[q].y * chk);
     }
     // the wave's GP x 64 results leave in the layout of the 2D FFT, f[z][ky][kx]: 4 slice pairs x 16 kx per store
     // (same-wave LDS exchange: no barrier needed, the compiler orders the ds operations of a wave)

@@ -1,5 +1,5 @@
 """Small fixed workloads for rocprofv3 --pmc passes (one kernel class per invocation, few launches).
-usage: python tools/pmc_probe.py <what> [N] [NZ] [NA]   what in {pdtv0,pdtv1,pdtv0h,roftv,bp0,bp1,fp,momentum}"""
+usage: python tools/pmc_probe.py <what> [N] [NZ] [NA]   what in {pdtv0,pdtv1,pdtv0h,roftv,bp0,bp1,fp,momentum,fourier}"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,6 +32,10 @@ elif what.startswith("stream"):   # stream<nin><nout>[v] e.g. stream54 (dword) /
     po = (C.c_void_p * 8)(*[t.data_ptr() for t in outs])
     for _ in range(3):
         lib.tomo_diag_stream(pi, nin, po, nout, vol.numel(), 4 if what.endswith("v") else 1, 2048, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+elif what == "fourier":
+    from tomobar_amd.methodsDIR_CuPy import RecToolsDIRCuPy
+    rt = RecToolsDIRCuPy(N, 0, NZ, 0.0, np.linspace(0, np.pi, NA, endpoint=False), N, device_projector=0)
+    rt.FOURIER_INV(torch.rand((NZ, NA, N), device="cuda"))
 elif what == "momentum":
     for _ in range(4):
         ops.momentum(vol, out, out, 0.5)
