@@ -53,7 +53,7 @@ struct PlanKey {
 struct PlanEntry { PlanKey key; hipfftHandle h; };
 std::mutex g_plan_mu;
 std::vector<PlanEntry> g_plans;
-enum { PLAN_R2C = 0, PLAN_C2R = 1, PLAN_C2C_1D = 2, PLAN_C2C_2D = 3 };
+enum { PLAN_C2C_1D = 2, PLAN_C2C_2D = 3 };
 
 int get_plan(int device, int kind, int len, int batch, hipStream_t st, hipfftHandle *out)
 {
@@ -68,9 +68,7 @@ int get_plan(int device, int kind, int len, int batch, hipStream_t st, hipfftHan
     hipfftHandle h = 0;
     int dims[2] = {len, len};
     hipfftResult r;
-    if (kind == PLAN_R2C) r = hipfftPlanMany(&h, 1, dims, nullptr, 1, len, nullptr, 1, len / 2 + 1, HIPFFT_R2C, batch);
-    else if (kind == PLAN_C2R) r = hipfftPlanMany(&h, 1, dims, nullptr, 1, len / 2 + 1, nullptr, 1, len, HIPFFT_C2R, batch);
-    else if (kind == PLAN_C2C_1D) r = hipfftPlanMany(&h, 1, dims, nullptr, 1, len, nullptr, 1, len, HIPFFT_C2C, batch);
+    if (kind == PLAN_C2C_1D) r = hipfftPlanMany(&h, 1, dims, nullptr, 1, len, nullptr, 1, len, HIPFFT_C2C, batch);
     else r = hipfftPlanMany(&h, 2, dims, nullptr, 1, len * len, nullptr, 1, len * len, HIPFFT_C2C, batch);
     if (r != HIPFFT_SUCCESS) return tomo_fail(TOMO_E_RUNTIME, "hipfftPlanMany(kind %d, len %d, batch %d) failed: %d", kind, len, batch, (int)r);
     if (hipfftSetStream(h, st) != HIPFFT_SUCCESS) { (void)hipfftDestroy(h); return tomo_fail(TOMO_E_RUNTIME, "hipfftSetStream failed"); }
@@ -81,43 +79,49 @@ int get_plan(int device, int kind, int len, int batch, hipStream_t st, hipfftHan
 constexpr float PI_F = 3.1415926535897932384626433832795f;  // fft_us_kernels.cu:2
 
 // ---- filter stage -------------------------------------------------------------------------------------------------
-// buf[r][j] = in[r][clamp(j - pad_m)]  (cp.pad(..., mode="edge"), methodsDIR_CuPy.py:522-530)
-__global__ __launch_bounds__(256) void pad_edge_kernel(const float *__restrict__ in, float *__restrict__ buf, size_t rows,
-                                                       int raw_n, int ne, int pad_m)
+// The filter of methodsDIR_CuPy.py:479-534 has a REAL impulse response (a real, even window times the phase ramp of a
+// shift), so the two slices of a pair can be filtered together as one complex signal a + i b: one complex transform per
+// pair instead of two real ones (hipFFT's real transforms are a half-length complex transform plus a pre/post pass that
+// cost more than the transform itself here).  The spectrum of the pair is multiplied by the Hermitian extension of the
+// half-spectrum table.
+// cbuf[r][j] = (a[clamp(j - pad_m)], b[clamp(j - pad_m)]): edge padding (cp.pad(..., mode="edge"), :522-530) + pairing;
+// pair-row r = z_local * nproj + p, a = slice 2(c0 + z_local), b = the next slice.
+__global__ __launch_bounds__(256) void pad_pair_kernel(const float *__restrict__ in, float2 *__restrict__ cbuf, size_t rows,
+                                                       size_t row_first, int nproj, int raw_n, int ne, int pad_m)
 {
     const size_t total = rows * (size_t)ne, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const size_t r = i / ne;
         const int j = (int)(i - r * ne);
-        buf[i] = in[r * raw_n + min(max(j - pad_m, 0), raw_n - 1)];
+        const size_t row = row_first + r;
+        const size_t z = row / nproj, p = row - z * nproj;
+        const int x = min(max(j - pad_m, 0), raw_n - 1);
+        const float *pa = in + ((2 * z) * nproj + p) * raw_n + x;
+        cbuf[i] = make_float2(pa[0], pa[(size_t)nproj * raw_n]);
     }
 }
 
-__global__ __launch_bounds__(256) void mul_filter_kernel(float2 *spec, const float2 *__restrict__ w, size_t rows, int nh)
+__global__ __launch_bounds__(256) void mul_filter_kernel(float2 *spec, const float2 *__restrict__ w, size_t rows, int ne)
 {
-    const size_t total = rows * (size_t)nh, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t total = rows * (size_t)ne, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const float2 g = w[i % nh], v = spec[i];
+        const float2 g = w[i % ne], v = spec[i];
         spec[i] = make_float2(g.x * v.x - g.y * v.y, g.x * v.y + g.y * v.x);
     }
 }
 
-// Centre crop of the filtered rows, 1/ne of the unnormalised inverse transform, pairing of slices (2z, 2z+1) into one
-// complex slice and the first fftshift sign (r2c_c1dfftshift, fft_us_kernels.cu:519-548).
-// Rows of this sub-chunk: row = (slice_local * nproj + p), slice_local = row0_slice + ...; datac[z][p][x]
-__global__ __launch_bounds__(256) void crop_pair_kernel(const float *__restrict__ buf, float2 *__restrict__ datac, size_t rows,
-                                                        size_t row_first, int nproj, int n, int ne, int unpad_m, float inv_ne)
+// Centre crop of the filtered pair-rows, 1/ne of the unnormalised inverse transform and the first fftshift sign
+// (r2c_c1dfftshift, fft_us_kernels.cu:519-548) into datac[z][p][x].
+__global__ __launch_bounds__(256) void crop_pair_kernel(const float2 *__restrict__ cbuf, float2 *__restrict__ datac, size_t rows,
+                                                        size_t row_first, int n, int ne, int unpad_m, float inv_ne)
 {
     const size_t total = rows * (size_t)n, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const size_t r = i / n;
         const int x = (int)(i - r * n);
-        const size_t row = row_first + r;           // row in the chunk: slice_local * nproj + p
-        const size_t sl = row / nproj, p = row - sl * nproj;
-        const float sgn = (x & 1) ? 1.0f : -1.0f;
-        const float v = buf[r * ne + unpad_m + x] * inv_ne * sgn;
-        float *dst = reinterpret_cast<float *>(datac + ((sl >> 1) * nproj + p) * n + x);
-        dst[sl & 1] = v;
+        const float s = ((x & 1) ? 1.0f : -1.0f) * inv_ne;
+        const float2 v = cbuf[r * ne + unpad_m + x];
+        datac[(row_first + r) * n + x] = make_float2(v.x * s, v.y * s);
     }
 }
 
@@ -519,17 +523,17 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
     const int nzh = nz / 2, nh = ne / 2 + 1, two_n = 2 * n;
     const int zc_max = std::min(nzh, FZ);
     // filter sub-chunks: at most ~64 Mi floats in the padded buffer
-    const size_t chunk_rows = (size_t)2 * zc_max * nproj;
+    const size_t chunk_rows = (size_t)zc_max * nproj;  // pair-rows
     const size_t rows_sub = std::max<size_t>(1, std::min<size_t>(chunk_rows, ((size_t)64 << 20) / ne));
-    const size_t bytes_buf = rows_sub * (size_t)ne * sizeof(float);
-    const size_t bytes_spec = rows_sub * (size_t)nh * sizeof(float2);
+    const size_t bytes_buf = rows_sub * (size_t)ne * sizeof(float2);
+    const size_t bytes_spec = 0;
     const size_t bytes_datac = (size_t)zc_max * nproj * n * sizeof(float2);
     const size_t bytes_g = (size_t)nproj * n * FZ * sizeof(float2);
     const size_t bytes_f = (size_t)two_n * two_n * zc_max * sizeof(float2);
-    const size_t bytes_tab = ((size_t)nh * sizeof(float2) + (size_t)nproj * 4 * sizeof(float) + (size_t)nproj * sizeof(int) + 1024);
+    const size_t bytes_tab = ((size_t)ne * sizeof(float2) + (size_t)nproj * 4 * sizeof(float) + (size_t)nproj * sizeof(int) + 1024);
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     char *ws = nullptr;
-    hipfftHandle p_r2c = 0, p_c2r = 0, p_c2c = 0, p_2d = 0;
+    hipfftHandle p_filt = 0, p_c2c = 0, p_2d = 0;
     {   // workspace: the per-device grow-only scratch arena (shared with the TV operators, released by tomo_release_scratch)
         const size_t total = al(bytes_buf) + al(bytes_spec) + al(bytes_datac) + al(bytes_g) + al(bytes_f) + al(bytes_tab);
         void *base = nullptr;
@@ -538,14 +542,13 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
         ws = (char *)base;
     }
     {
-        float *buf = (float *)ws;
-        float2 *spec = (float2 *)(ws + al(bytes_buf));
-        float2 *datac = (float2 *)((char *)spec + al(bytes_spec));
+        float2 *cbuf = (float2 *)ws;
+        float2 *datac = (float2 *)(ws + al(bytes_buf) + al(bytes_spec));
         float2 *g = (float2 *)((char *)datac + al(bytes_datac));
         float2 *f = (float2 *)((char *)g + al(bytes_g));
         char *tab = (char *)f + al(bytes_f);
         float2 *w_dev = (float2 *)tab;
-        float *ct = (float *)(tab + al((size_t)nh * sizeof(float2)));
+        float *ct = (float *)(tab + al((size_t)ne * sizeof(float2)));
         float *sn = ct + nproj, *sth = sn + nproj;
         int *order = (int *)(sth + nproj);
 
@@ -555,7 +558,13 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
         for (int i = 0; i < nproj; ++i) { h_ct[i] = cosf(theta_host[i]); h_sn[i] = sinf(theta_host[i]); h_order[i] = i; }
         std::stable_sort(h_order.begin(), h_order.end(), [&](int p, int q) { return theta_host[p] < theta_host[q]; });
         for (int i = 0; i < nproj; ++i) h_sth[i] = theta_host[h_order[i]];
-        TOMO_HIPG(hipMemcpyAsync(w_dev, w_host, (size_t)nh * sizeof(float2), hipMemcpyHostToDevice, st));
+        // Hermitian extension of the half-spectrum filter table: W[ne - k] = conj(W[k])
+        std::vector<float2> h_w(ne);
+        for (int k = 0; k < nh; ++k) h_w[k] = make_float2(w_host[2 * k], w_host[2 * k + 1]);
+        for (int k = nh; k < ne; ++k) h_w[k] = make_float2(w_host[2 * (ne - k)], -w_host[2 * (ne - k) + 1]);
+        h_w[0].y = 0.0f;       // a real inverse transform ignores the imaginary part of the DC and Nyquist bins
+        h_w[ne / 2].y = 0.0f;  // (irfft, methodsDIR_CuPy.py:533): keep the two slices of a pair separate there too
+        TOMO_HIPG(hipMemcpyAsync(w_dev, h_w.data(), (size_t)ne * sizeof(float2), hipMemcpyHostToDevice, st));
         TOMO_HIPG(hipMemcpyAsync(ct, h_ct.data(), nproj * sizeof(float), hipMemcpyHostToDevice, st));
         TOMO_HIPG(hipMemcpyAsync(sn, h_sn.data(), nproj * sizeof(float), hipMemcpyHostToDevice, st));
         TOMO_HIPG(hipMemcpyAsync(sth, h_sth.data(), nproj * sizeof(float), hipMemcpyHostToDevice, st));
@@ -566,18 +575,17 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
         const float phi_scale = (float)(1 - n % 4) / (float)nproj;
         for (int c0 = 0; c0 < nzh; c0 += FZ) {
             const int zc = std::min(FZ, nzh - c0);
-            const size_t rows = (size_t)2 * zc * nproj;
-            // ---- STEP 0: filter (methodsDIR_CuPy.py:449-545), output paired + shifted into datac[z][p][x]
+            const size_t rows = (size_t)zc * nproj;  // pair-rows of this chunk
+            // ---- STEP 0: filter (methodsDIR_CuPy.py:449-545), slice pairs as complex rows, output shifted into datac[z][p][x]
+            const float *chunk_in = data_dev + (size_t)2 * c0 * nproj * raw_n;
             for (size_t r0 = 0; r0 < rows; r0 += rows_sub) {
                 const size_t rs = std::min(rows_sub, rows - r0);
-                if ((rc = get_plan(device, PLAN_R2C, ne, (int)rs, st, &p_r2c)) != TOMO_OK) goto done;
-                if ((rc = get_plan(device, PLAN_C2R, ne, (int)rs, st, &p_c2r)) != TOMO_OK) goto done;
-                const float *src = data_dev + ((size_t)2 * c0 * nproj + r0) * raw_n;
-                pad_edge_kernel<<<2048, 256, 0, st>>>(src, buf, rs, raw_n, ne, pad_m);
-                TOMO_FFT(hipfftExecR2C(p_r2c, buf, (hipfftComplex *)spec));
-                mul_filter_kernel<<<2048, 256, 0, st>>>(spec, w_dev, rs, nh);
-                TOMO_FFT(hipfftExecC2R(p_c2r, (hipfftComplex *)spec, buf));
-                crop_pair_kernel<<<2048, 256, 0, st>>>(buf, datac, rs, r0, nproj, n, ne, crop_m, 1.0f / (float)ne);
+                if ((rc = get_plan(device, PLAN_C2C_1D, ne, (int)rs, st, &p_filt)) != TOMO_OK) goto done;
+                pad_pair_kernel<<<2048, 256, 0, st>>>(chunk_in, cbuf, rs, r0, nproj, raw_n, ne, pad_m);
+                TOMO_FFT(hipfftExecC2C(p_filt, (hipfftComplex *)cbuf, (hipfftComplex *)cbuf, HIPFFT_FORWARD));
+                mul_filter_kernel<<<2048, 256, 0, st>>>(cbuf, w_dev, rs, ne);
+                TOMO_FFT(hipfftExecC2C(p_filt, (hipfftComplex *)cbuf, (hipfftComplex *)cbuf, HIPFFT_BACKWARD));
+                crop_pair_kernel<<<2048, 256, 0, st>>>(cbuf, datac, rs, r0, n, ne, crop_m, 1.0f / (float)ne);
             }
             // ---- STEP 1: 1D FFT along the detector (methodsDIR_CuPy.py:723-724)
             if ((rc = get_plan(device, PLAN_C2C_1D, n, zc * nproj, st, &p_c2c)) != TOMO_OK) goto done;

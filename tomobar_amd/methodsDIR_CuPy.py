@@ -197,9 +197,9 @@ class RecToolsDIRCuPy:
         if dry:
             itemsize = np.dtype(kwargs.get("data_dtype", np.float32)).itemsize
             zc = min(nz_even // 2, 64)
-            rows_sub = max(1, min(2 * zc * nproj, (64 << 20) // ne))
+            rows_sub = max(1, min(zc * nproj, (64 << 20) // ne))
             sizes = [int(np.prod(shape)) * itemsize, nz_even * nproj * raw_n * 4 if (odd_horiz or odd_vert) else 0,
-                     rows_sub * ne * 4, rows_sub * (ne // 2 + 1) * 8, zc * nproj * n * 8, nproj * n * 64 * 8,
+                     rows_sub * ne * 8, 0, zc * nproj * n * 8, nproj * n * 64 * 8,
                      (2 * n) * (2 * n) * zc * 8, int(np.prod(out_shape)) * 4]
             for b in sizes:
                 if b:
