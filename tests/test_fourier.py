@@ -172,3 +172,25 @@ def test_FOURIER_INV_errors_and_dry_run(golden):
     with DeviceMemStack() as stack:
         shape = rt.FOURIER_INV((4, 20, 32), data_dtype=np.float32)
     assert shape == (4, 32, 32) and stack.highwater > 4 * 20 * 32 * 4 and stack.current == (4 * 20 * 32 * 4 + 4 * 32 * 32 * 4)
+
+
+@pytest.mark.gpu
+def test_FOURIER_INV_medium_size_not_a_power_of_two(FO):
+    """200-wide detector (grid 400^2: partial 64-column tiles and 8-point blocks), a prime number of angles over an
+    arbitrary range, rotation-axis offset, reconstruction smaller than the detector: whole-grid centre gathering"""
+    import torch
+    from tomobar_amd.methodsDIR_CuPy import RecToolsDIRCuPy
+    nz, nproj, dn, rs, cor = 6, 97, 200, 180, 1.7
+    angles = 0.4 + np.linspace(0, 1.1 * np.pi, nproj, endpoint=False)
+    rng = np.random.default_rng(8)
+    sino = rng.random((nz, nproj, dn), dtype=np.float32)
+    rt = RecToolsDIRCuPy(dn, 0, nz, cor, angles, rs, device_projector=0)
+    rec = rt.FOURIER_INV(torch.from_numpy(sino).cuda(), filter_type="cosine", cutoff_freq=0.9).cpu().numpy()
+    want = FO.fourier_inv(sino, angles, cor, rs, filter_type="cosine", cutoff_freq=0.9)
+    assert rec.shape == want.shape == (nz, rs, rs)
+    assert rel(rec, want) < TOL
+    # horizontal detector padding of the class (DetectorsDimH_pad) widens the Fourier grid: n = 200 + 2 * 12
+    rtp = RecToolsDIRCuPy(dn, 12, nz, cor, angles, rs, device_projector=0)
+    recp = rtp.FOURIER_INV(torch.from_numpy(sino).cuda()).cpu().numpy()
+    wantp = FO.fourier_inv(sino, angles, cor, rs, detectors_x_pad=12)
+    assert rel(recp, wantp) < TOL
