@@ -211,6 +211,10 @@ int tomo_pdtv_pair_slab_range(int device, const float *in_dev, const float *u_in
 int tomo_roftv_iter_slab(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
                          int dx, int dy, int nz_local, int lo_planes, int hi_planes,
                          float lambda, float tau, int half, void *stream);
+/* Same for the local output planes [z_begin, z_end) only (boundary planes first, exchange, then the interior). */
+int tomo_roftv_iter_slab_range(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
+                               int dx, int dy, int nz_local, int lo_planes, int hi_planes, int z_begin, int z_end,
+                               float lambda, float tau, int half, void *stream);
 
 /* ---------------------------------------------------------------- FBP filter
  * tomo_fbp_filter replaces _filtersinc3D_cupy (tomobar/fourier.py:26-78) and generate_filtersinc

@@ -268,14 +268,16 @@ def pd_pair_slab(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, lo, hi, sigma, tau,
         p_out[c][lo + z0:lo + z1] = torch.from_numpy(p2[c][lo + z0:lo + z1]).to(p_out[c].dtype)
 
 
-def rof_step_slab(inp, u_in, u_out, dx, dy, nzl, lo, hi, lam, tau, half):
-    """One ROF_TV iteration on a ghosted z-slab (signature of tomobar_amd.slab._hip_rof_step)."""
+def rof_step_slab(inp, u_in, u_out, dx, dy, nzl, lo, hi, lam, tau, half, zr=None):
+    """One ROF_TV iteration on a ghosted z-slab (signature of tomobar_amd.slab._hip_rof_step); ``zr`` restricts the
+    written local planes (tomo_roftv_iter_slab_range)."""
     L = lib()
     fp = C.POINTER(C.c_float)
     L.orc_roftv_step.argtypes = [fp] * 3 + [C.c_int] * 7 + [C.c_float] * 2 + [C.c_int]
     L.orc_roftv_step.restype = None
-    L.orc_roftv_step(_fptr(inp.numpy()), _fptr(u_in.numpy()), _fptr(u_out.numpy()), dx, dy, nzl + lo + hi, lo,
-                     lo + nzl, 0 if lo else 1, 0 if hi else 1, lam, tau, int(bool(half)))
+    z0, z1 = zr if zr is not None else (0, nzl)
+    L.orc_roftv_step(_fptr(inp.numpy()), _fptr(u_in.numpy()), _fptr(u_out.numpy()), dx, dy, nzl + lo + hi, lo + z0,
+                     lo + z1, 0 if lo else 1, 0 if hi else 1, lam, tau, int(bool(half)))
 
 
 def prox(X, reg, nonneg_regul):

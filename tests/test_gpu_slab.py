@@ -93,6 +93,14 @@ def test_roftv_slabs_equal_whole_volume(world, half):
         states.append(RofSlab(vd[z0:z1].contiguous(), r > 0, r < world - 1, half, _hip_rof_step))
     _copy_halos(states, 0)
     for it in range(iters):
+        if it % 2:  # every other iteration in the overlapped order: boundary planes, "exchange", interior
+            for s in states:
+                for zr in s.boundary_ranges()[0]:
+                    s.step(it, np.float32(0.05), np.float32(0.005), zr)
+            _copy_halos(states, (it + 1) & 1)
+            for s in states:
+                s.step(it, np.float32(0.05), np.float32(0.005), s.boundary_ranges()[1])
+            continue
         for s in states:
             s.step(it, np.float32(0.05), np.float32(0.005))
         _copy_halos(states, (it + 1) & 1)

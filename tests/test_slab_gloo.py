@@ -60,6 +60,7 @@ CASES = [
     dict(kind="pd", shape=(19, 6, 13), iters=7, mtv=0, nn=1, half=False),
     dict(kind="pd", shape=(26, 5, 12), iters=6, mtv=0, nn=0, half=True),
     dict(kind="rof", shape=(9, 7, 11), iters=6, half=False),
+    dict(kind="rof", shape=(22, 6, 10), iters=5, half=False),   # long enough for the overlapped schedule
     dict(kind="rof", shape=(10, 5, 9), iters=4, half=True),
 ]
 

@@ -75,6 +75,7 @@ SIGNATURES = {
     "tomo_pdtv_pair_slab_range": (_i, [_i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i,
                                        _f, _f, _f, _f, _i, _i, _i, _vp]),
     "tomo_roftv_iter_slab": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
+    "tomo_roftv_iter_slab_range": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "tomo_fbp_filter": (_i, [_i, _vp, _sz, _i, _f, _f, _vp]),
     "tomo_fourier_inv": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _f, _i, _vp]),
     "tomo_set_variant": (_i, [C.c_char_p, _i]),

@@ -648,7 +648,17 @@ extern "C" int tomo_roftv_iter_slab(int device, const float *in_dev, const float
                                     int dx, int dy, int nz_local, int lo_planes, int hi_planes,
                                     float lambda, float tau, int half, void *stream)
 {
+    return tomo_roftv_iter_slab_range(device, in_dev, u_in_dev, u_out_dev, dx, dy, nz_local, lo_planes, hi_planes, 0,
+                                      nz_local, lambda, tau, half, stream);
+}
+
+extern "C" int tomo_roftv_iter_slab_range(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
+                                          int dx, int dy, int nz_local, int lo_planes, int hi_planes, int z_begin,
+                                          int z_end, float lambda, float tau, int half, void *stream)
+{
     TOMO_REQUIRE(device >= 0 && dx >= 2 && dy >= 2 && nz_local > 0, "bad slab arguments");
+    TOMO_REQUIRE(z_begin >= 0 && z_begin <= z_end && z_end <= nz_local, "bad output plane range [%d, %d)", z_begin, z_end);
+    if (z_begin == z_end) return TOMO_OK;
     TOMO_REQUIRE((lo_planes == 0 || lo_planes == 2) && (hi_planes == 0 || hi_planes == 1),
                  "ROF slab needs 0 or 2 ghost planes below and 0 or 1 above");
     TOMO_HIP(hipSetDevice(device));
@@ -656,8 +666,8 @@ extern "C" int tomo_roftv_iter_slab(int device, const float *in_dev, const float
     a.in = in_dev; a.u_in = u_in_dev; a.u_out = u_out_dev;
     a.dx = dx; a.dy = dy;
     a.planes = nz_local + lo_planes + hi_planes;
-    a.out_begin = lo_planes;
-    a.out_end = lo_planes + nz_local;
+    a.out_begin = lo_planes + z_begin;
+    a.out_end = lo_planes + z_end;
     a.first_is_edge = lo_planes ? 0 : 1;
     a.last_is_edge = hi_planes ? 0 : 1;
     a.lambda = lambda; a.tau = tau;

@@ -299,9 +299,20 @@ class RofSlab:
     def local(self, t):
         return t[self.lo:self.lo + self.nzl]
 
-    def step(self, it, lam, tau):
-        self.step_fn(self.inp, self.U[it & 1], self.U[(it + 1) & 1], self.dx, self.dy, self.nzl, self.lo, self.hi,
-                     lam, tau, self.half)
+    def step(self, it, lam, tau, zr=None):
+        """iteration ``it``: buffer it&1 -> (it+1)&1, all local planes or only the local range ``zr``"""
+        if zr is None:
+            self.step_fn(self.inp, self.U[it & 1], self.U[(it + 1) & 1], self.dx, self.dy, self.nzl, self.lo, self.hi,
+                         lam, tau, self.half)
+        elif zr[1] > zr[0]:
+            self.step_fn(self.inp, self.U[it & 1], self.U[(it + 1) & 1], self.dx, self.dy, self.nzl, self.lo, self.hi,
+                         lam, tau, self.half, zr)
+
+    def boundary_ranges(self):
+        """planes the neighbours wait for (first plane below an interior boundary, last two above one) and the rest"""
+        b0 = 1 if self.lo else 0
+        b1 = self.nzl - (2 if self.hi else 0)
+        return ([(0, b0)] if self.lo else []) + ([(b1, self.nzl)] if self.hi else []), (b0, b1)
 
     def send_down(self, b):
         return [self.U[b][self.lo]]
@@ -317,26 +328,37 @@ class RofSlab:
         return [self.U[b][self.lo + self.nzl]] if self.hi else []
 
 
-def _hip_rof_step(inp, u_in, u_out, dx, dy, nzl, lo, hi, lam, tau, half):
+def _hip_rof_step(inp, u_in, u_out, dx, dy, nzl, lo, hi, lam, tau, half, zr=None):
     from . import _lib as L
     from . import ops
+    z0, z1 = zr if zr is not None else (0, nzl)
     with torch.cuda.device(inp.device):
-        L.check(L.lib().tomo_roftv_iter_slab(inp.device.index, ops.ptr(inp), ops.ptr(u_in), ops.ptr(u_out), dx, dy, nzl,
-                                             int(lo), int(hi), float(lam), float(tau), int(bool(half)),
-                                             ops.stream_ptr(inp)))
+        L.check(L.lib().tomo_roftv_iter_slab_range(inp.device.index, ops.ptr(inp), ops.ptr(u_in), ops.ptr(u_out), dx, dy,
+                                                   nzl, int(lo), int(hi), int(z0), int(z1), float(lam), float(tau),
+                                                   int(bool(half)), ops.stream_ptr(inp)))
 
 
 def rof_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, time_marching_parameter,
-                half_precision=False, step_fn: Optional[Callable] = None, out=None):
+                half_precision=False, step_fn: Optional[Callable] = None, out=None, overlap: bool = True):
     if data.shape[0] < 2 and (comm.has_lo or comm.has_hi):
         raise ValueError("ROF_TV slabs must hold at least two slices")
     st = RofSlab(data, comm.has_lo, comm.has_hi, half_precision, step_fn or _hip_rof_step)
     lam, tau = np.float32(regularisation_parameter), np.float32(time_marching_parameter)
     comm.exchange(st.send_down(0), st.recv_down(0), st.send_up(0), st.recv_up(0))
+    edge_ranges, interior = st.boundary_ranges()
+    overlap = overlap and bool(edge_ranges) and interior[1] - interior[0] >= 4
     for it in range(iterations):
+        more = it + 1 < iterations
+        b = (it + 1) & 1
+        if overlap and more:  # boundary planes, exchange in flight, interior (see pd_tv_slab)
+            for zr in edge_ranges:
+                st.step(it, lam, tau, zr)
+            reqs = comm.exchange_start(st.send_down(b), st.recv_down(b), st.send_up(b), st.recv_up(b))
+            st.step(it, lam, tau, interior)
+            comm.exchange_wait(reqs)
+            continue
         st.step(it, lam, tau)
-        if it + 1 < iterations:
-            b = (it + 1) & 1
+        if more:
             comm.exchange(st.send_down(b), st.recv_down(b), st.send_up(b), st.recv_up(b))
     res = st.local(st.U[iterations & 1])
     if out is not None:
