@@ -235,11 +235,8 @@ static int fp_window_bound(const tomo_angle_t *tab, const int *order, int n_clas
 }
 
 // ---- synchronous (non-pipelined) form: stage kc rows, barrier, sample, barrier.  Small LDS footprint, so many
-//      workgroups per CU hide the staging latency instead of a register prefetch.  Variant 2 (A/B measurement).
-// BT = workgroup size = detector pixels per workgroup (256 / 512 / 1024): a wider detector tile amortises the part of
-// the window that comes from the angular spread of the group over more rays.
-// A = angles sampled per staged row (8, or 20 when the angular spread of a subset makes the window a whole row anyway:
-// more angles per staged byte and more sampling work per barrier)
+//      workgroups per CU hide the staging latency instead of a register prefetch.  Fallback for windows wider than the
+//      pipelined kernel supports, and variant 2 for A/B measurement (1024^3 x 75 angles: 22.8 ms vs 15.6 ms pipelined).
 template <bool LERP8, bool RESID, int BT, int A>
 __global__ __launch_bounds__(BT) void fp_tiled_sync_kernel(FpTiledArgs a, int kc)
 {

@@ -465,44 +465,16 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 t.nzb = ceil_div(a.nz, 4);
                 const long blocks = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
                 TOMO_REQUIRE(blocks <= 0x7fffffffL, "problem too large for one FP launch");
-                // Narrow windows (dense angle sets: <= 2 column passes) run the register-prefetch pipeline; wide
-                // windows (ordered subsets spread the angles of a group) run the synchronous form, whose small LDS
-                // footprint lets many workgroups per CU hide the staging latency.  Measured on MI355X:
-                // 512^3 x 360 angles 8.4 ms (pipelined) vs 10.0 (sync); 1024^3 x 75 angles 22 ms (sync).
+                // Windows of up to 1280 columns run the register-prefetch pipeline (double-buffered up to 512 columns,
+                // single-buffered beyond); wider ones (detectors wider than 1024 whose whole-row form does not fit in
+                // LDS) and variant 2 run the synchronous form: stage, barrier, sample, barrier, with a small LDS
+                // footprint so that several workgroups per CU hide the staging latency.
                 static const int pipe_max = getenv("TOMO_FP_PIPE_MAX") ? atoi(getenv("TOMO_FP_PIPE_MAX")) : FP_MAX_WPITCH;
                 if (g_variant_fp == 2 || t.wpitch > std::min(pipe_max, FP_MAX_WPITCH)) {
-                    static const int lds_budget = getenv("TOMO_FP_LDS") ? atoi(getenv("TOMO_FP_LDS")) : 40000;
-                    // wide windows: a wider detector tile (more threads per workgroup) shares the spread-induced part
-                    static const int bt_env = getenv("TOMO_FP_BT") ? atoi(getenv("TOMO_FP_BT")) : 0;
-                    static const int ga_env = getenv("TOMO_FP_A") ? atoi(getenv("TOMO_FP_A")) : 0;
-                    int bt = bt_env ? bt_env : 256;
-                    if (bt != 256 && bt != 512 && bt != 1024) bt = 256;
-                    // wide windows (angular spread of an ordered subset): sample 20 angles per staged row
-                    // measured (1024^3 x 75): 8 angles per row 22.6 ms; 20 angles 36-65 ms (register file: the
-                    // 80 accumulators + prefetch no longer stay in VGPRs)
-                    const int ga = (ga_env == 8 || ga_env == 20) ? ga_env : 8;
-                    if (bt > 256 || ga != FP_A) {
-                        t.wpitch = fp_window_bound(ctx->host_table.data() + s.table_offset,
-                                                   ctx->host_fp_order.data() + order_off, nc, ctx->n, ctx->nu, bt, ga);
-                        t.nut = ceil_div(a.nu, bt);
-                        t.ngroups = ceil_div(nc, ga);
-                    }
-                    const long blocks_s = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
-                    const int kcs = std::max(1, std::min(8, lds_budget / (t.wpitch * 16)));
+                    const int kcs = std::max(1, std::min(8, 40000 / (t.wpitch * 16)));
                     const size_t sm = (size_t)kcs * t.wpitch * 16;
                     TOMO_REQUIRE(sm <= 64 * 1024, "forward-projection window does not fit in LDS");
-#define FP_SYNC_LAUNCH(L8, RES)                                                                                   \
-    do {                                                                                                          \
-        if (ga == 20) {                                                                                           \
-            if (bt == 256) fp_tiled_sync_kernel<L8, RES, 256, 20><<<(unsigned)blocks_s, 256, sm, st>>>(t, kcs);   \
-            else if (bt == 512) fp_tiled_sync_kernel<L8, RES, 512, 20><<<(unsigned)blocks_s, 512, sm, st>>>(t, kcs); \
-            else fp_tiled_sync_kernel<L8, RES, 1024, 20><<<(unsigned)blocks_s, 1024, sm, st>>>(t, kcs);           \
-        } else {                                                                                                  \
-            if (bt == 256) fp_tiled_sync_kernel<L8, RES, 256, 8><<<(unsigned)blocks_s, 256, sm, st>>>(t, kcs);    \
-            else if (bt == 512) fp_tiled_sync_kernel<L8, RES, 512, 8><<<(unsigned)blocks_s, 512, sm, st>>>(t, kcs); \
-            else fp_tiled_sync_kernel<L8, RES, 1024, 8><<<(unsigned)blocks_s, 1024, sm, st>>>(t, kcs);            \
-        }                                                                                                         \
-    } while (0)
+#define FP_SYNC_LAUNCH(L8, RES) fp_tiled_sync_kernel<L8, RES, 256, FP_A><<<(unsigned)blocks, 256, sm, st>>>(t, kcs)
                     if (b) { if (l8) FP_SYNC_LAUNCH(true, true); else FP_SYNC_LAUNCH(false, true); }
                     else   { if (l8) FP_SYNC_LAUNCH(true, false); else FP_SYNC_LAUNCH(false, false); }
 #undef FP_SYNC_LAUNCH
