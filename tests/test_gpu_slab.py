@@ -43,11 +43,11 @@ def test_pdtv_slabs_equal_whole_volume(world, half, variant):
             for r in range(world):
                 z0, z1 = slab_bounds(nz, world, r)
                 states.append(PdSlab(vd[z0:z1].contiguous(), r > 0, r < world - 1, half, _hip_pd_pair, _hip_pd_step))
-            for r in range(world - 1):  # static Input ghosts and the ghosts of the initial primal variable
+            for r in range(world - 1):  # the exchange before the first step: two planes of Input either side
                 lo, hi = states[r], states[r + 1]
-                for src, dst in zip(lo.input_send_up() + lo.send_up(0)[:2], hi.input_recv_down() + hi.recv_down(0)[:2]):
+                for src, dst in zip(lo.initial_send_up(), hi.initial_recv_down()):
                     dst.copy_(src)
-                for src, dst in zip(hi.input_send_down() + hi.send_down(0)[:2], lo.input_recv_up() + lo.recv_up(0)[:2]):
+                for src, dst in zip(hi.initial_send_down(), lo.initial_recv_up()):
                     dst.copy_(src)
             it = 0
             while it < iters:

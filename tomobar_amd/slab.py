@@ -117,8 +117,9 @@ class PdSlab:
         # overwritten before it is read (the outermost Input ghost only feeds warm-up values that are discarded)
         self.inp = torch.empty((planes, dy, dx), dtype=torch.float32, device=dev)
         self.inp[self.lo:self.lo + nzl] = data
+        # the first step reads its primal variable from ``inp`` (U^0 = Input), so U[0] needs no initial copy
         self.U = [torch.empty((planes, dy, dx), dtype=torch.float32, device=dev) for _ in range(2)]
-        self.U[0][self.lo:self.lo + nzl] = data
+        self.first = True
         self.P = [[torch.zeros((planes, dy, dx), dtype=pd, device=dev) for _ in range(3)],
                   [torch.empty((planes, dy, dx), dtype=pd, device=dev) for _ in range(3)]]
         self.pair_fn, self.step_fn = pair_fn, step_fn
@@ -128,7 +129,7 @@ class PdSlab:
         return t[self.lo:self.lo + self.nzl]
 
     def result(self) -> torch.Tensor:
-        return self.local(self.U[self.cur])
+        return self.local(self.inp if self.first else self.U[self.cur])
 
     def pair(self, sigma, tau, lt, theta, methodTV, nonneg):
         self.pair_range(sigma, tau, lt, theta, methodTV, nonneg, 0, self.nzl)
@@ -138,11 +139,15 @@ class PdSlab:
         """Two iterations for the local output planes [z_begin, z_end) only (buffer set cur -> cur ^ 1, no flip)."""
         i, o = self.cur, self.cur ^ 1
         if z_end > z_begin:
-            self.pair_fn(self.inp, self.U[i], self.U[o], self.P[i], self.P[o], self.dx, self.dy, self.nzl, self.lo,
+            self.pair_fn(self.inp, self._u_in(), self.U[o], self.P[i], self.P[o], self.dx, self.dy, self.nzl, self.lo,
                          self.hi, sigma, tau, lt, theta, methodTV, nonneg, self.half, (z_begin, z_end))
+
+    def _u_in(self) -> torch.Tensor:
+        return self.inp if self.first else self.U[self.cur]
 
     def flip(self):
         self.cur ^= 1
+        self.first = False
 
     def boundary_ranges(self):
         """Local plane ranges whose results the neighbours wait for (two planes at an interior boundary) and the rest."""
@@ -157,10 +162,10 @@ class PdSlab:
         s = 1 if self.has_lo else 0
         n = self.nzl + (1 if self.has_lo else 0) + (1 if self.has_hi else 0)
         v = lambda t: t[s:s + n]  # noqa: E731
-        self.step_fn(v(self.inp), v(self.U[i]), v(self.U[o]), [v(p) for p in self.P[i]], [v(p) for p in self.P[o]],
+        self.step_fn(v(self.inp), v(self._u_in()), v(self.U[o]), [v(p) for p in self.P[i]], [v(p) for p in self.P[o]],
                      self.dx, self.dy, self.nzl, self.has_lo, self.has_hi, sigma, tau, lt, theta, methodTV, nonneg,
                      self.half)
-        self.cur = o
+        self.flip()
 
     # ---- ghost planes of buffer set b.  Up = to rank+1 (its lo ghosts), down = to rank-1 (its hi ghosts).
     def send_up(self, b: int):
@@ -192,18 +197,21 @@ class PdSlab:
         h = self.lo + self.nzl
         return [self.U[b][h], self.U[b][h + 1]] + [self.P[b][c][h] for c in range(3)]
 
-    # static Input ghosts: the nearer plane either side
-    def input_send_up(self):
-        return [self.inp[self.lo + self.nzl - 1]] if self.has_hi else []
+    # ---- the one exchange before the first step: two planes of Input either side (they are the ghosts of the initial
+    #      primal variable as well, U^0 = Input); the initial duals are zero everywhere
+    def initial_send_down(self):
+        return [self.inp[self.lo], self.inp[self.lo + 1]] if self.has_lo else []
 
-    def input_recv_down(self):
-        return [self.inp[1]] if self.has_lo else []
+    def initial_recv_down(self):
+        return [self.inp[0], self.inp[1]] if self.has_lo else []
 
-    def input_send_down(self):
-        return [self.inp[self.lo]] if self.has_lo else []
+    def initial_send_up(self):
+        l1 = self.lo + self.nzl - 1
+        return [self.inp[l1 - 1], self.inp[l1]] if self.has_hi else []
 
-    def input_recv_up(self):
-        return [self.inp[self.lo + self.nzl]] if self.has_hi else []
+    def initial_recv_up(self):
+        h = self.lo + self.nzl
+        return [self.inp[h], self.inp[h + 1]] if self.has_hi else []
 
 
 def _ptr3(ts):
@@ -242,9 +250,7 @@ def pd_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, m
     theta = np.float32(1.0)
     lt = np.float32(tau / regularisation_parameter)
     st = PdSlab(data, comm.has_lo, comm.has_hi, half_precision, pair_fn or _hip_pd_pair, step_fn or _hip_pd_step)
-    # Input ghosts (static) and the ghosts of the initial primal variable; the initial duals are zero everywhere
-    comm.exchange(st.input_send_down() + st.send_down(0)[:2], st.input_recv_down() + st.recv_down(0)[:2],
-                  st.input_send_up() + st.send_up(0)[:2], st.input_recv_up() + st.recv_up(0)[:2])
+    comm.exchange(st.initial_send_down(), st.initial_recv_down(), st.initial_send_up(), st.initial_recv_up())
     it = 0
     edge_ranges, interior = st.boundary_ranges()
     # Overlap: the planes the neighbours wait for are computed first (two thin launches), their exchange runs on RCCL's
@@ -270,11 +276,13 @@ def pd_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, m
         if it < iterations:
             b = st.cur
             comm.exchange(st.send_down(b), st.recv_down(b), st.send_up(b), st.recv_up(b))
-    res = st.result()
+    res = st.result()  # a view of the last output buffer (the buffer lives as long as the view)
+    if iterations == 0:
+        res = data
     if out is not None:
         out.copy_(res)
         return out
-    return res.clone()
+    return res
 
 
 # ------------------------------------------------------------------------------------------------ ROF_TV on a slab
