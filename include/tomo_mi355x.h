@@ -82,6 +82,10 @@ int tomo_ctx_subset_size(const tomo_ctx *ctx, int subset);
 int tomo_ctx_angle_table(const tomo_ctx *ctx, int subset, tomo_angle_t *out_host, int capacity);
 /* release the context's scratch arena (cp._default_memory_pool.free_all_blocks(), methodsIR_CuPy.py:425) */
 int tomo_ctx_release_scratch(tomo_ctx *ctx);
+/* diagnostics: which kernel form the LAST tomo_fp3d* ("fp") / tomo_bp3d* ("bp") call on this context took, e.g.
+ * "y:whole-row(1024 threads, 3 passes, 3 rows/chunk) ...".  The library also prints one stderr warning per process when
+ * a slow fallback form is taken.  (No reference counterpart: ASTRA picks its kernels internally, astra_base.py:554,601.) */
+const char *tomo_ctx_kernel_path(const tomo_ctx *ctx, const char *op);
 
 /* ---------------------------------------------------------------- projector pair
  * tomo_fp3d  replaces AstraBase.runAstraProj3DCuPy  (astra_base.py:560-606, direct_FP3D :601)

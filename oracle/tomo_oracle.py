@@ -392,6 +392,31 @@ def admm(P: Projector, b, iterations, lipschitz_const, rho=1.0, relax=1.6, nonne
     return x
 
 
+def osem(P: Projector, b, iterations, nonnegativity=False, reg=None, x0=None):
+    """methodsIR_CuPy.py:618-658 (OSEM; MLEM when os_number == 1): start from ones (dicts / __common_initialisation
+    for method_run="OSEM"), ``normalisation = clip(A_0^T 1, 1e-8)`` from subset 0 only (:626-637), multiplicative update
+    ``x *= A_s^T(b_s / clip(A_s x, 1e-8)) * normalisation`` (:648-654 -- the reference multiplies where the textbook
+    form divides; restated as written), then the proximal step."""
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    eps = np.float32(1e-8)
+    use_os = P.os_number > 1
+    x = np.ones((P.nz, P.n, P.n), np.float32) if x0 is None else np.array(x0, dtype=np.float32)
+    sub0 = 0 if use_os else None
+    n0 = len(P.subsets[0]) if use_os else P.na
+    normalisation = np.clip(P.bp(np.ones((P.nz, n0, P.nu), np.float32), sub0), eps, None)
+    for _ in range(iterations):
+        for s in range(P.os_number):
+            sub = s if use_os else None
+            idx = P.subsets[s] if use_os else slice(None)
+            ax = np.clip(P.fp(x, sub), eps, None)
+            ratio = (b[:, idx, :] / ax).astype(np.float32, copy=False)
+            back = P.bp(np.ascontiguousarray(ratio), sub)
+            x = x * (back * normalisation)
+            if reg is not None and reg.get("method") is not None:
+                x = prox(x, reg, 1 if nonnegativity else 0)
+    return x
+
+
 # ------------------------------------------------------------------ FBP (SURVEY 8f-1)
 def sinc_filter(n, cutoff, multiplier):
     """Half-spectrum, fftshift-ed sinc-ramp filter in float32: generate_filtersync.cu:5-82 / methodsDIR.py:295-312."""

@@ -1,0 +1,147 @@
+"""TEST INFRASTRUCTURE: lets the product's Python drivers (RecToolsIRCuPy.FISTA / ADMM / powermethod, dicts_check, the
+slab TV drivers) run in a GPU-less process by standing the ORACLE in for the C-ABI library at the two seams the drivers
+use -- the projector object (``HipTools3D``) and the ``tomobar_amd.ops`` module.  Only the multi-process gloo tests use
+it (tests/test_slab_gloo.py): what they check is the drivers' control flow, slab bookkeeping and collectives, which are
+the same Python lines on the GPU.  Nothing here is reachable from the product package."""
+import types
+
+import numpy as np
+import torch
+
+from oracle import tomo_oracle as O
+
+
+def _np(t):
+    return t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def _put(dst: torch.Tensor, arr):
+    dst.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).view(dst.shape))
+    return dst
+
+
+class OracleTools3D:
+    """The HipTools3D interface the iterative drivers use, computed by the oracle projector on CPU tensors."""
+
+    def __init__(self, detectors_x, detectors_x_pad, detectors_y, angles_vec, centre_of_rotation, recon_size,
+                 processing_arch="gpu", device_index=0, ordsub_number=None, lerp8=False):
+        self.detectors_x_pad = int(detectors_x_pad)
+        self.device_index = int(device_index)
+        self.nz, self.n = int(detectors_y), int(recon_size)
+        self.nu = int(detectors_x) + 2 * self.detectors_x_pad
+        self.ordsub_number = 1 if ordsub_number is None else int(ordsub_number)
+        self.P = O.Projector(self.nz, self.n, self.nu, np.asarray(angles_vec, np.float64), centre_of_rotation,
+                             self.ordsub_number)
+        self.na = self.P.na
+        self._device = torch.device("cpu")
+        self.vol_geom = {"GridRowCount": self.n, "GridColCount": self.n, "GridSliceCount": self.nz}
+
+    def _idx(self, os_index):
+        return slice(None) if (os_index is None or self.ordsub_number == 1) else self.P.subsets[os_index]
+
+    def _sub(self, os_index):
+        return None if (os_index is None or self.ordsub_number == 1) else int(os_index)
+
+    def subset_size(self, os_index):
+        return self.na if self._sub(os_index) is None else len(self.P.subsets[os_index])
+
+    def vol_shape(self):
+        return (self.nz, self.n, self.n)
+
+    def sino_shape(self, os_index=None):
+        return (self.nz, self.subset_size(os_index), self.nu)
+
+    def forward(self, vol, os_index=None, out=None):
+        r = self.P.fp(np.ascontiguousarray(_np(vol)), self._sub(os_index))
+        return torch.from_numpy(r) if out is None else _put(out, r)
+
+    def backward(self, sino, os_index=None, out=None):
+        r = self.P.bp(np.ascontiguousarray(_np(sino)), self._sub(os_index))
+        return torch.from_numpy(r) if out is None else _put(out, r)
+
+    def residual(self, vol, b, w, fidelity, os_index, out, gathered=0):
+        ax = self.P.fp(np.ascontiguousarray(_np(vol)), self._sub(os_index))
+        idx = self._idx(os_index)
+        bs = _np(b)[:, idx, :]
+        if fidelity in ("LS", "PWLS"):
+            r = ax - bs
+            if w is not None:
+                r = r * _np(w)[:, idx, :]
+        elif fidelity == "KL":
+            r = np.float32(1) - bs / np.clip(ax, np.float32(1e-8), None)
+        else:
+            r = bs / np.clip(ax, np.float32(1e-8), None)
+        return _put(out, r)
+
+    def grad_step(self, res, x_t, x_out, l_inv, nonneg, os_index):
+        x = _np(x_t) - np.float32(l_inv) * self.P.bp(np.ascontiguousarray(_np(res)), self._sub(os_index))
+        if nonneg:
+            np.maximum(x, 0, out=x)
+        _put(x_out, x)
+
+    def grad_step_momentum(self, res, x_t, x_old_then_x, l_inv, beta, nonneg, os_index):
+        x = _np(x_t) - np.float32(l_inv) * self.P.bp(np.ascontiguousarray(_np(res)), self._sub(os_index))
+        if nonneg:
+            np.maximum(x, 0, out=x)
+        xt = x + np.float32(beta) * (x - _np(x_old_then_x))
+        _put(x_old_then_x, x)
+        _put(x_t, xt)
+
+    def admm_z_update(self, res, z, x, u, zu_out, tau, rho, relax_on, one_minus_alpha, alpha, nonneg, os_index):
+        g = self.P.bp(np.ascontiguousarray(_np(res)), self._sub(os_index))
+        z0, xn, un = _np(z).copy(), _np(x), _np(u)
+        ga = np.float32(rho) * (z0 - xn + un)
+        zn = z0 - np.float32(tau) * (g + ga)
+        if nonneg:
+            np.maximum(zn, 0, out=zn)
+        if relax_on:
+            zn = np.float32(one_minus_alpha) * z0 + np.float32(alpha) * zn
+        _put(z, zn)
+        _put(zu_out, zn + un)
+
+
+def make_ops():
+    """A stand-in for the ``tomobar_amd.ops`` module on CPU tensors (numpy float32 arithmetic, the oracle's TV)."""
+    m = types.ModuleType("cpu_ops")
+    m.to_device = lambda x, device_index=0: x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+    m.contiguous = lambda t: t.contiguous()
+    m.fill = lambda x, v: x.fill_(float(v))
+    m.momentum = lambda x, xo, xt, beta: _put(xt, _np(x) + np.float32(beta) * (_np(x) - _np(xo)))
+    m.admm_dual = lambda u, z, x: _put(u, _np(u) + (_np(z) - _np(x)))
+    m.scale = lambda a, x, y: _put(y, np.float32(a) * _np(x))
+    m.clamp_min = lambda x, lo=0.0: x.clamp_(min=float(lo))
+    m.norm2 = lambda x: float(np.sqrt(np.sum(_np(x).astype(np.float64) ** 2)))
+    m.dot = lambda x, y: float(np.sum(_np(x).astype(np.float64) * _np(y)))
+
+    def pwls_weights(b, slab=None):
+        w = np.maximum(_np(b), np.float32(1e-6))
+        wmax = w.max() if slab is None else np.float32(slab.allreduce_max(float(w.max())))
+        return torch.from_numpy(w / wmax)
+
+    m.pwls_weights = pwls_weights
+    m.pad_edge = lambda b, pad: torch.from_numpy(O.pad_detector(_np(b), pad))
+    m.crop_center = lambda v, size: torch.from_numpy(np.ascontiguousarray(O.crop_recon(_np(v), size)))
+    m.circ_mask_ = lambda v, radius: _put(v, O.circular_mask(_np(v), radius))
+
+    def pdtv(data, out, sigma, tau, lt, theta, iterations, methodTV, nonneg, half):
+        raise AssertionError("whole-volume TV must not be called on a slab rank")
+
+    m.pdtv = m.roftv = pdtv
+    return m
+
+
+def install(monkeypatch=None):
+    """Point the drivers at the stand-ins (module attributes; undone by pytest's monkeypatch when given)."""
+    import tomobar_amd.methodsIR_CuPy as IR
+    import tomobar_amd.regularisersCuPy as REG
+    import tomobar_amd.slab as SL
+    import tomobar_amd.supp.dicts as DI
+    import tomobar_amd.supp.suppTools as ST
+    ops = make_ops()
+    sets = [(IR, "ops", ops), (IR, "HipTools3D", OracleTools3D), (REG, "ops", ops), (DI, "ops", ops), (ST, "ops", ops),
+            (SL, "_hip_pd_pair", O.pd_pair_slab), (SL, "_hip_pd_step", O.pd_step_slab), (SL, "_hip_rof_step", O.rof_step_slab)]
+    for mod, name, val in sets:
+        if monkeypatch is not None:
+            monkeypatch.setattr(mod, name, val)
+        else:
+            setattr(mod, name, val)

@@ -98,7 +98,10 @@ def ref_tv_lib():
     return L
 
 
-def main():
+def setup():
+    """Install the plumbing shims, import the reference driver and return ``make(detH, pad, detV, cor, angles, objsize,
+    os_number)``: a factory of REFERENCE RecToolsIRCuPy objects with the oracle projector plugged in at the Atools seam
+    and the reference's own TV kernel sources (host-executed) behind PD_TV_cupy / ROF_TV_cupy."""
     install_shims()
     import tomobar.regularisersCuPy as reg_mod
     from tomobar.methodsIR_CuPy import RecToolsIRCuPy
@@ -143,6 +146,11 @@ def main():
         A._backprojOSCuPy = lambda b, os_index: P.bp(np.ascontiguousarray(b), os_index)
         return R
 
+    return make
+
+
+def main():
+    make = setup()
     store = {}
     rng = np.random.default_rng(11)
     nz, n, na = 4, 24, 30

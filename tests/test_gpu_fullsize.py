@@ -88,3 +88,61 @@ def test_config3_shape_projector_pair_against_oracle(oracle):
     got = H.backward(torch.from_numpy(base_s).cuda() * sc, None)
     want = torch.from_numpy(P1.bp(base_s, None)).cuda() * sc
     assert torch.equal(got, want), float((got - want).abs().max())
+
+
+def test_config5_shape_per_gpu(oracle):
+    """BASELINE configs[4] per-GPU shape (2560-wide detector, 2560^2 slices, 1800 angles in 12 subsets = 150 angles per
+    subset, a 50-slice piece of a rank's 270-slice slab -- ragged last z-brick and slice quad): forward projection (plain
+    and with the PWLS residual epilogue), back projection (plain and with the FISTA epilogue) through the power-of-two
+    slice-scaling property against the one-slice oracle, and PD_TV / ROF_TV at 2560^2 through the z-invariance property.
+    Also pins WHICH forward-projection kernel this shape takes: the whole-row pipelined form, not a silent fallback."""
+    from tomobar_amd.projector import HipTools3D
+    from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
+    n, nz, na, os_n = 2560, 50, 1800, 12
+    angles = np.linspace(0, np.pi, na, endpoint=False)
+    H = HipTools3D(n, 0, nz, angles, 1.75, n, "gpu", 0, os_n)
+    P1 = oracle.Projector(1, n, n, angles, 1.75, os_n)
+    assert H.subset_size(5) == 150
+    rng = np.random.default_rng(5)
+    base_v = rng.random((1, n, n), dtype=np.float32)
+    sc = _scales(nz, "cuda")
+    vol = torch.from_numpy(base_v).cuda() * sc
+    for sub in (0, 5):
+        want = torch.from_numpy(P1.fp(base_v, sub)).cuda() * sc
+        got = H.forward(vol, sub)
+        path = H.kernel_path("fp")
+        assert torch.equal(got, want), (sub, float((got - want).abs().max()))
+        assert "whole-row" in path and "march" not in path and "sync" not in path, path
+    print("configs[4] forward-projection path:", path)
+    # residual epilogue (PWLS) on subset 5: full-sinogram b / w are addressed through the subset's angle indices
+    idx = P1.subsets[5]
+    b_full = torch.zeros((nz, na, n), dtype=torch.float32, device="cuda")
+    w_full = torch.zeros_like(b_full)
+    bs = torch.from_numpy(rng.random((1, len(idx), n), dtype=np.float32)).cuda() * sc
+    wsub = torch.from_numpy((2.0 ** rng.integers(-2, 2, size=(1, len(idx), n))).astype(np.float32)).cuda().expand(nz, -1, -1)
+    b_full[:, torch.from_numpy(idx).cuda(), :] = bs
+    w_full[:, torch.from_numpy(idx).cuda(), :] = wsub
+    res = torch.empty((nz, len(idx), n), dtype=torch.float32, device="cuda")
+    H.residual(vol, b_full, w_full, "PWLS", 5, res)
+    assert torch.equal(res, (want - bs) * wsub)
+    del b_full, w_full, res, got
+    base_s = rng.standard_normal((1, len(P1.subsets[3]), n)).astype(np.float32)
+    sino = torch.from_numpy(base_s).cuda() * sc
+    want = torch.from_numpy(P1.bp(base_s, 3)).cuda() * sc
+    got = H.backward(sino, 3)
+    assert torch.equal(got, want), float((got - want).abs().max())
+    assert "brick" in H.kernel_path("bp"), H.kernel_path("bp")
+    out = torch.empty_like(got)
+    H.grad_step(sino, torch.zeros_like(got), out, np.float32(1.0 / 4096.0), True, 3)
+    assert torch.equal(out, torch.clamp(-(np.float32(1.0 / 4096.0) * want), min=0))
+    del got, want, out, sino, vol
+    # TV at 2560^2 (43 x-segments of 60 columns, ragged last segment): z-invariant volume -> the 2D operator's result
+    base = (rng.random((n, n), dtype=np.float32) * 0.3 + (np.indices((n, n))[1] > n // 2)).astype(np.float32)
+    v3 = torch.from_numpy(base).cuda().unsqueeze(0).expand(nz, n, n).contiguous()
+    for iters in (4, 5):
+        got3 = PD_TV_cupy(v3, 0.04, iters, 0, 1, 12.0, 0, False)
+        want2 = torch.from_numpy(oracle.pd_tv(base, 0.04, iters, 0, 1, 12.0, False)).cuda()
+        assert torch.equal(got3, want2.view(1, n, n).expand_as(got3)), float((got3 - want2.view(1, n, n)).abs().max())
+    got3 = ROF_TV_cupy(v3, 0.04, 3, 0.005, 0, False)
+    want2 = torch.from_numpy(oracle.rof_tv(base, 0.04, 3, 0.005, False)).cuda()
+    assert torch.equal(got3, want2.view(1, n, n).expand_as(got3))

@@ -218,6 +218,46 @@ def test_dir_forwproj_backproj(oracle, geom):
     P = oracle.Projector(geom["nz"], geom["n"], geom["n"], geom["angles"])
     vol = np.random.default_rng(0).random((geom["nz"], geom["n"], geom["n"])).astype(np.float32)
     assert rel(host(rt.FORWPROJ(torch.from_numpy(vol).cuda())), P.fp(vol)) < 1e-6
+    # the OUTPUT axis order of FORWPROJ follows data_axes_labels_order like the reference's (methodsDIR_CuPy.py:84-88)
+    for labels, perm in ((["angles", "detY", "detX"], (1, 0, 2)), (["detX", "angles", "detY"], (2, 1, 0)),
+                         (["detY", "angles", "detX"], (0, 1, 2))):
+        out = rt.FORWPROJ(torch.from_numpy(vol).cuda(), data_axes_labels_order=labels)
+        assert out.is_contiguous()
+        assert np.array_equal(host(out), np.transpose(P.fp(vol), perm)), labels
     swapped = torch.from_numpy(geom["sino"]).cuda().permute(1, 0, 2)  # a strided [angles, detY, detX] view
     got = rt.BACKPROJ(swapped, data_axes_labels_order=["angles", "detY", "detX"])
     assert rel(host(got), P.bp(geom["sino"])) < 1e-6
+
+
+OSEM_CASES = {
+    # name: (os_number, algorithm dict, regularisation)
+    "mlem": (None, dict(iterations=3), None),
+    "osem_os4": (4, dict(iterations=2), None),
+    "osem_os7_mask": (7, dict(iterations=1, recon_mask_radius=0.9), None),
+    "osem_os4_pdtv": (4, dict(iterations=2, nonnegativity=True), dict(method="PD_TV", regul_param=0.002, iterations=6)),
+    "mlem_roftv": (None, dict(iterations=2), dict(method="ROF_TV", regul_param=0.002, iterations=5,
+                                                  time_marching_step=0.002)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(OSEM_CASES))
+def test_osem_against_reference_python_loop(oracle, golden_dir, name):
+    """RecToolsIRCuPy.OSEM vs the fixture made by the REFERENCE's own OSEM loop (make_osem_golden.py;
+    methodsIR_CuPy.py:587-667), and bit for bit vs the oracle's restatement."""
+    g = np.load(os.path.join(golden_dir, "osem_golden.npz"))
+    os_n, alg, reg = OSEM_CASES[name]
+    sino, angles = g["sino"], g["angles"]
+    nz, _, n = sino.shape
+    from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    rt = RecToolsIRCuPy(n, 0, nz, 0.0, angles, n, 0, os_n)
+    d = {"projection_data": torch.from_numpy(sino).cuda(), "data_axes_labels_order": ["detY", "angles", "detX"]}
+    rec = rt.OSEM(d, dict(alg), None if reg is None else dict(reg))
+    got = host(rec)
+    assert got.dtype == np.float32 and got.shape == (nz, n, n)
+    assert rel(got, g[name]) < TOL, rel(got, g[name])
+    P = oracle.Projector(nz, n, n, angles, 0.0, os_n or 1)
+    full_reg = None if reg is None else {"regul_param": 0.001, "iterations": 150, "time_marching_step": 0.005,
+                                         "PD_LipschitzConstant": 12.0, "methodTV": 0, **reg}
+    want = oracle.circular_mask(oracle.osem(P, sino, alg["iterations"], alg.get("nonnegativity", False), full_reg),
+                                alg.get("recon_mask_radius", 1.0))
+    assert np.array_equal(got, want), np.abs(got - want).max()

@@ -1,0 +1,111 @@
+"""Second, independent pin of the TV operators: the REFERENCE's own kernel sources
+(/root/reference/tomobar/cuda_kernels/{primal_dual_for_total_variation,rudin_osher_fatemi_total_variation}.cu), compiled
+unmodified for gfx950 by hipcc with the ROCm toolchain's own headers (oracle/Makefile -> oracle/_ref/libref_tv_hip*.so,
+built where /root/reference exists and shipped to the GPU box as a binary) and EXECUTED ON THE MI355X with the reference's
+launch geometry, versus
+  (1) tests/golden/tv_golden.npz -- the same sources executed on the host by make_tv_golden.py (two execution models of
+      one source must agree), and
+  (2) libtomo_mi355x.so's PD_TV / ROF_TV on the same inputs (<= 1e-5 relative L2, the north-star tolerance).
+The summary that a run prints is committed under profiles/ (r2_ref_tv_hip_crosscheck.txt)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+fp = C.POINTER(C.c_float)
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def load(name):
+    path = os.path.join(ROOT, "oracle", "_ref", name)
+    if not os.path.exists(path):
+        pytest.skip(f"{path} is built from /root/reference (make -C oracle ref) and shipped as a binary; not present")
+    L = C.CDLL(path)
+    L.ref_pdtv.argtypes = [fp, fp] + [C.c_int] * 4 + [C.c_float] * 4 + [C.c_int] * 4
+    L.ref_roftv.argtypes = [fp, fp] + [C.c_int] * 4 + [C.c_float] * 2 + [C.c_int] * 2
+    return L
+
+
+def dims(d):
+    return (d.shape[1], d.shape[0], 1, 2) if d.ndim == 2 else (d.shape[2], d.shape[1], d.shape[0], 3)
+
+
+def ref_pd(L, O, data, lam, iters, mtv, nn, lip, half):
+    d, is2d, ax = O._squeeze_2d(data)
+    d = np.ascontiguousarray(d)
+    sg, tau, lt, th = O.pd_scalars(lam, lip)
+    out = np.empty_like(d)
+    dx, dy, dz, nd = dims(d)
+    assert L.ref_pdtv(O._fptr(d), O._fptr(out), dx, dy, dz, nd, sg, tau, lt, th, iters, mtv, nn, half) == 0
+    return np.expand_dims(out, ax) if is2d else out
+
+
+def ref_rof(L, O, data, lam, iters, tms, half):
+    d, is2d, ax = O._squeeze_2d(data)
+    d = np.ascontiguousarray(d)
+    out = np.empty_like(d)
+    dx, dy, dz, nd = dims(d)
+    assert L.ref_roftv(O._fptr(d), O._fptr(out), dx, dy, dz, nd, np.float32(lam), np.float32(tms), iters, half) == 0
+    return np.expand_dims(out, ax) if is2d else out
+
+
+def cases(tv, kind):
+    return sorted(int(k.split("_")[1]) for k in tv.files if k.startswith(kind + "_") and k.endswith("_meta"))
+
+
+@pytest.mark.parametrize("build", ["off", "fma"])
+def test_reference_tv_source_on_mi355x(oracle, golden_dir, build):
+    from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
+    L = load("libref_tv_hip.so" if build == "off" else "libref_tv_hip_fma.so")
+    tv = np.load(os.path.join(golden_dir, "tv_golden.npz"))
+    worst = {"pd_vs_golden": 0.0, "pd_vs_product": 0.0, "rof_vs_golden": 0.0, "rof_vs_product": 0.0}
+    exact = {"pd": 0, "rof": 0}
+    npd = nrof = 0
+    for cid in cases(tv, "pd"):
+        in_id, half, mtv, nn, iters, lam, lip = tv[f"pd_{cid}_meta"]
+        x = tv[f"in_{int(in_id)}"]
+        if nn:
+            x = (x - 0.6).astype(np.float32)
+        ref = ref_pd(L, oracle, x, float(lam), int(iters), int(mtv), int(nn), float(lip), int(half))
+        r_g = rel(ref, tv[f"pd_{cid}_{build}"])
+        got = PD_TV_cupy(torch.from_numpy(x).cuda(), float(lam), int(iters), int(mtv), int(nn), float(lip), 0, bool(half))
+        torch.cuda.synchronize()
+        r_p = rel(got.cpu().numpy(), ref)
+        worst["pd_vs_golden"] = max(worst["pd_vs_golden"], r_g)
+        worst["pd_vs_product"] = max(worst["pd_vs_product"], r_p)
+        exact["pd"] += int(np.array_equal(ref, tv[f"pd_{cid}_{build}"]))
+        npd += 1
+        assert r_g < TOL, ("PD reference-on-GPU vs host-executed reference", cid, r_g)
+        assert r_p < TOL, ("PD product vs reference-on-GPU", cid, r_p)
+    for cid in cases(tv, "rof"):
+        in_id, half, iters, lam, tms = tv[f"rof_{cid}_meta"]
+        x = tv[f"in_{int(in_id)}"]
+        ref = ref_rof(L, oracle, x, float(lam), int(iters), float(tms), int(half))
+        r_g = rel(ref, tv[f"rof_{cid}_{build}"])
+        got = ROF_TV_cupy(torch.from_numpy(x).cuda(), float(lam), int(iters), float(tms), 0, bool(half))
+        torch.cuda.synchronize()
+        r_p = rel(got.cpu().numpy(), ref)
+        worst["rof_vs_golden"] = max(worst["rof_vs_golden"], r_g)
+        worst["rof_vs_product"] = max(worst["rof_vs_product"], r_p)
+        exact["rof"] += int(np.array_equal(ref, tv[f"rof_{cid}_{build}"]))
+        nrof += 1
+        assert r_g < TOL, ("ROF reference-on-GPU vs host-executed reference", cid, r_g)
+        assert r_p < TOL, ("ROF product vs reference-on-GPU", cid, r_p)
+    line = (f"ref-TV-on-MI355X build={build}: {npd} PD cases, {nrof} ROF cases; worst rel-L2 {worst}; "
+            f"bit-identical to the host-executed golden: PD {exact['pd']}/{npd}, ROF {exact['rof']}/{nrof}")
+    print(line)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"ref_tv_hip_crosscheck_{build}.txt"), "w") as f:
+        f.write(line + "\n")

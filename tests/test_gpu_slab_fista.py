@@ -1,0 +1,93 @@
+"""Two OS processes, one z-slab each, driving the PRODUCT path end to end: RecToolsIRCuPy.powermethod / FISTA / ADMM with
+``rt.slab`` set, i.e. the HIP kernels of libtomo_mi355x.so + the slab TV drivers + the scalar all-reduces (power-method
+norm, PWLS maximum) together, against the oracle's WHOLE-volume reconstruction.
+
+The GPU box has one MI355X, and RCCL refuses two ranks on one device, so the ranks share cuda:0 and talk over gloo
+(tomobar_amd.slab stages the ghost planes through the host for that backend): every line of the multi-rank control flow
+runs, only the transport differs from the 8-GPU run (backend "nccl", exercised by `bench.py --gpus N` on a multi-GPU
+node)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.multiprocessing as mp  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, case):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import tomo_oracle as O
+        from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+        from tomobar_amd.slab import SlabComm, slab_bounds
+        dev = torch.device("cuda", 0)
+        nz, n, na, os_n = case["nz"], 40, 36, case["os"]
+        angles = np.linspace(0, np.pi, na, endpoint=False)
+        rng = np.random.default_rng(2)
+        sino = np.abs(O.shepp_logan_sino(n, nz, n, angles) / n + 0.02 * rng.standard_normal((nz, na, n))).astype(np.float32)
+        P = O.Projector(nz, n, n, angles, 0.0, os_n)
+        z0, z1 = slab_bounds(nz, world, rank)
+        rt = RecToolsIRCuPy(n, 0, z1 - z0, 0.0, angles, n, 0, os_n if os_n > 1 else None)
+        rt.slab = SlabComm(rank, world, dev)
+        assert rt.slab.staged
+        # ---- power method over the slabs: the dominant eigenvalue of the WHOLE operator
+        rt.power_seed = 3
+        L_slab = rt.powermethod({"projection_data": None})
+        L_whole = O.power_method(P, rng.standard_normal((nz, n, n)).astype(np.float32))
+        np.testing.assert_allclose(L_slab, L_whole, rtol=1e-4)
+        # ---- reconstruction with a given Lipschitz constant: bit-identical to the whole-volume oracle
+        reg = dict(case["reg"])
+        full_reg = {"regul_param": 0.001, "iterations": 150, "time_marching_step": 0.005, "PD_LipschitzConstant": 12.0,
+                    "methodTV": 0, **reg}
+        d = {"projection_data": torch.from_numpy(sino[z0:z1].copy()).to(dev),
+             "data_axes_labels_order": ["detY", "angles", "detX"], "data_fidelity": case["fid"]}
+        if case["method"] == "FISTA":
+            want = O.fista(P, sino, 2, L_whole, True, full_reg, case["fid"])
+            got = rt.FISTA(d, {"iterations": 2, "lipschitz_const": L_whole, "nonnegativity": True,
+                               "recon_mask_radius": None}, reg)
+        else:
+            want = O.admm(P, sino, 3, L_whole, 1.0, 1.6, False, full_reg, case["fid"])
+            got = rt.ADMM(d, {"iterations": 3, "lipschitz_const": L_whole, "recon_mask_radius": None}, reg)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        assert got.shape == (z1 - z0, n, n)
+        assert np.array_equal(got, want[z0:z1]), (rank, float(np.abs(got - want[z0:z1]).max()))
+        # ---- Lipschitz constant computed inside (power method + all-reduce) and used by FISTA: close to the oracle's run
+        got2 = rt.FISTA(dict(d), {"iterations": 1, "nonnegativity": True, "recon_mask_radius": None}, reg)
+        want2 = O.fista(P, sino, 1, L_whole, True, full_reg, case["fid"])
+        torch.cuda.synchronize()
+        r = np.linalg.norm(got2.cpu().numpy() - want2[z0:z1]) / max(np.linalg.norm(want2[z0:z1]), 1e-30)
+        assert r < 1e-3, r
+    finally:
+        dist.destroy_process_group()
+
+
+CASES = [
+    dict(method="FISTA", nz=11, os=4, fid="PWLS", reg=dict(method="PD_TV", regul_param=0.002, iterations=7)),
+    dict(method="FISTA", nz=12, os=1, fid="LS", reg=dict(method="ROF_TV", regul_param=0.002, iterations=5,
+                                                         time_marching_step=0.002)),
+    dict(method="ADMM", nz=16, os=3, fid="LS", reg=dict(method="PD_TV", regul_param=0.004, iterations=6)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['method']}-os{c['os']}-{c['fid']}-{c['reg']['method']}")
+def test_two_rank_reconstruction_matches_whole_volume(case):
+    mp.start_processes(_worker, args=(2, _free_port(), case), nprocs=2, join=True, start_method="spawn")

@@ -130,3 +130,27 @@ def test_power_method_vs_reference(oracle, outer):
     for key, os_n in (("L_full", 1), ("L_os4", 4), ("L_os7", 7)):
         P = oracle.Projector(nz, n, n, angles, 0.0, os_n)
         np.testing.assert_allclose(oracle.power_method(P, x), float(outer[key]), rtol=2e-5)
+
+
+OSEM_CASES = {
+    # name: (os_number, iterations, mask radius, nonnegativity, regularisation)
+    "mlem": (1, 3, 1.0, False, None),
+    "osem_os4": (4, 2, 1.0, False, None),
+    "osem_os7_mask": (7, 1, 0.9, False, None),
+    "osem_os4_pdtv": (4, 2, 1.0, True, dict(method="PD_TV", regul_param=0.002, iterations=6)),
+    "mlem_roftv": (1, 2, 1.0, False, dict(method="ROF_TV", regul_param=0.002, iterations=5, time_marching_step=0.002)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(OSEM_CASES))
+def test_osem_oracle_vs_reference_python(oracle, golden_dir, name):
+    """The reference's OSEM loop (methodsIR_CuPy.py:587-667, run unmodified by make_osem_golden.py) vs the oracle's."""
+    g = np.load(os.path.join(golden_dir, "osem_golden.npz"))
+    os_n, iters, radius, nonneg, reg = OSEM_CASES[name]
+    sino, angles = g["sino"], g["angles"]
+    nz, _, n = sino.shape
+    P = oracle.Projector(nz, n, n, angles, 0.0, os_n)
+    if reg is not None:
+        reg = {**REG_DEFAULTS, **reg}
+    got = oracle.circular_mask(oracle.osem(P, sino, iters, nonneg, reg), radius)
+    assert rel(got, g[name]) < TOL, rel(got, g[name])

@@ -71,9 +71,107 @@ def test_slab_tv_matches_whole_volume(world, case):
     mp.start_processes(_worker, args=(world, _free_port(), case), nprocs=world, join=True, start_method="spawn")
 
 
+def _fista_worker(rank, world, port, case):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import _cpu_backend
+        from oracle import tomo_oracle as O
+        _cpu_backend.install()
+        from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+        from tomobar_amd.slab import SlabComm, slab_bounds
+        nz, n, na, os_n = case["nz"], 20, 24, case["os"]
+        angles = np.linspace(0, np.pi, na, endpoint=False)
+        rng = np.random.default_rng(2)
+        sino = np.abs(O.shepp_logan_sino(n, nz, n, angles) / n + 0.02 * rng.standard_normal((nz, na, n))).astype(np.float32)
+        P = O.Projector(nz, n, n, angles, 0.0, os_n)
+        z0, z1 = slab_bounds(nz, world, rank)
+        rt = RecToolsIRCuPy(n, 0, z1 - z0, 0.0, angles, n, 0, os_n if os_n > 1 else None)
+        rt.slab = SlabComm(rank, world)
+        # power method: the eigenvector spans all slabs (norm all-reduced every iteration)
+        rt.power_seed = 3
+        L_slab = rt.powermethod({"projection_data": None})
+        L_whole = O.power_method(P, rng.standard_normal((nz, n, n)).astype(np.float32))
+        np.testing.assert_allclose(L_slab, L_whole, rtol=1e-4)
+        reg = dict(case["reg"])
+        full_reg = {"regul_param": 0.001, "iterations": 150, "time_marching_step": 0.005, "PD_LipschitzConstant": 12.0,
+                    "methodTV": 0, **reg}
+        d = {"projection_data": torch.from_numpy(sino[z0:z1].copy()), "data_axes_labels_order": ["detY", "angles", "detX"],
+             "data_fidelity": case["fid"]}
+        if case["method"] == "FISTA":
+            want = O.fista(P, sino, 2, L_whole, True, full_reg, case["fid"])
+            got = rt.FISTA(d, {"iterations": 2, "lipschitz_const": L_whole, "nonnegativity": True,
+                               "recon_mask_radius": None}, reg)
+        else:
+            want = O.admm(P, sino, 3, L_whole, 1.0, 1.6, False, full_reg, case["fid"])
+            got = rt.ADMM(d, {"iterations": 3, "lipschitz_const": L_whole, "recon_mask_radius": None}, reg)
+        assert np.array_equal(got.numpy(), want[z0:z1]), (rank, float(np.abs(got.numpy() - want[z0:z1]).max()))
+    finally:
+        dist.destroy_process_group()
+
+
+FISTA_CASES = [
+    dict(method="FISTA", nz=9, os=4, fid="PWLS", reg=dict(method="PD_TV", regul_param=0.002, iterations=7)),
+    dict(method="FISTA", nz=8, os=1, fid="LS", reg=dict(method="ROF_TV", regul_param=0.002, iterations=5,
+                                                        time_marching_step=0.002)),
+    dict(method="ADMM", nz=10, os=3, fid="LS", reg=dict(method="PD_TV", regul_param=0.004, iterations=6)),
+]
+
+
+@pytest.mark.parametrize("case", FISTA_CASES, ids=lambda c: f"{c['method']}-os{c['os']}-{c['fid']}-{c['reg']['method']}")
+def test_slab_reconstruction_drivers_match_whole_volume(case):
+    """world-2 gloo run of RecToolsIRCuPy.powermethod / FISTA / ADMM with ``rt.slab`` set: power-method all-reduce, PWLS
+    maximum all-reduce and the slab proximal step together; the oracle stands in for the C-ABI library at the projector /
+    ops seams (tests/_cpu_backend.py), every driver line is the product's."""
+    mp.start_processes(_fista_worker, args=(2, _free_port(), case), nprocs=2, join=True, start_method="spawn")
+
+
+def _short_slab_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import tomo_oracle as O
+        from tomobar_amd.slab import SlabComm, pd_tv_slab, rof_tv_slab, slab_bounds
+        comm = SlabComm(rank, world)
+        z0, z1 = slab_bounds(5, world, rank)          # 2 + 2 + 1 slices: the last slab is too short for two-plane ghosts
+        mine = torch.zeros((z1 - z0, 4, 6))
+        for fn, kw in ((pd_tv_slab, dict(pair_fn=O.pd_pair_slab, step_fn=O.pd_step_slab)),
+                       (rof_tv_slab, dict(step_fn=O.rof_step_slab))):
+            comm._validated.clear()
+            try:
+                if fn is pd_tv_slab:
+                    fn(mine, comm, 0.04, 4, 0, 0, 8.0, False, **kw)
+                else:
+                    fn(mine, comm, 0.04, 4, 0.005, False, **kw)
+            except ValueError as e:   # EVERY rank raises (nobody is left waiting in a send/recv)
+                assert "fewer than 2 slices" in str(e)
+            else:
+                raise AssertionError(f"rank {rank}: a too-short slab must raise on all ranks")
+        dist.barrier()                                 # all ranks got here: no deadlock
+    finally:
+        dist.destroy_process_group()
+
+
+def test_short_slab_raises_on_every_rank_instead_of_deadlocking():
+    mp.start_processes(_short_slab_worker, args=(3, _free_port()), nprocs=3, join=True, start_method="spawn")
+
+
 def test_slab_bounds_cover_volume():
     from tomobar_amd.slab import slab_bounds
     for nz, world in ((10, 3), (1024, 8), (2160, 8), (5, 8)):
         b = [slab_bounds(nz, world, r) for r in range(world)]
         assert b[0][0] == 0 and b[-1][1] == nz
         assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        sizes = [z1 - z0 for z0, z1 in b]
+        assert max(sizes) - min(sizes) <= 1, "balanced split: no rank is short while another holds a full share"
+    from tomobar_amd.slab import check_slab_split
+    check_slab_split(16, 8)
+    with pytest.raises(ValueError):
+        check_slab_split(15, 8)

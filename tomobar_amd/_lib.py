@@ -38,6 +38,7 @@ SIGNATURES = {
     "tomo_ctx_subset_size": (_i, [_vp, _i]),
     "tomo_ctx_angle_table": (_i, [_vp, _i, C.POINTER(AngleRecord), _i]),
     "tomo_ctx_release_scratch": (_i, [_vp]),
+    "tomo_ctx_kernel_path": (C.c_char_p, [_vp, C.c_char_p]),
     "tomo_fp3d": (_i, [_vp, _i, _vp, _vp, _vp]),
     "tomo_bp3d": (_i, [_vp, _i, _vp, _vp, _vp]),
     "tomo_fp3d_residual": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),

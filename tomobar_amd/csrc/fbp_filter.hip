@@ -8,6 +8,9 @@
 #include <hipfft/hipfft.h>
 
 #include <cmath>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 namespace {
@@ -61,7 +64,71 @@ std::vector<float> make_filter(int n, float a, float mult)
     return f;
 }
 
+// hipFFT plan pairs per (device, nu, rows) and device filter tables per (device, nu, cutoff, multiplier) are kept
+// between calls (plan creation costs more than the transforms of a small batch); tomo_release_scratch frees them
+struct fbp_plans { hipfftHandle fwd = 0, inv = 0; };
+std::mutex g_fbp_mu;
+std::map<std::tuple<int, int, size_t>, fbp_plans> g_fbp_plans;
+std::map<std::tuple<int, int, float, float>, float *> g_fbp_filters;
+
+int fbp_get_plans(int device, int nu, size_t rows, fbp_plans &out)
+{
+    const auto key = std::make_tuple(device, nu, rows);
+    auto it = g_fbp_plans.find(key);
+    if (it != g_fbp_plans.end()) { out = it->second; return TOMO_OK; }
+    const int nh = nu / 2 + 1;
+    int n[1] = {nu};
+    fbp_plans p;
+    hipfftResult r = hipfftPlanMany(&p.fwd, 1, n, nullptr, 1, nu, nullptr, 1, nh, HIPFFT_R2C, (int)rows);
+    if (r == HIPFFT_SUCCESS) r = hipfftPlanMany(&p.inv, 1, n, nullptr, 1, nh, nullptr, 1, nu, HIPFFT_C2R, (int)rows);
+    if (r != HIPFFT_SUCCESS) {  // nothing half-built is kept or leaked
+        if (p.fwd) (void)hipfftDestroy(p.fwd);
+        if (p.inv) (void)hipfftDestroy(p.inv);
+        return tomo_fail(TOMO_E_RUNTIME, "hipfftPlanMany failed: hipfft status %d", (int)r);
+    }
+    g_fbp_plans[key] = p;
+    out = p;
+    return TOMO_OK;
+}
+
+int fbp_get_filter(int device, int nu, float cutoff, float multiplier, const float **out)
+{
+    const auto key = std::make_tuple(device, nu, cutoff, multiplier);
+    auto it = g_fbp_filters.find(key);
+    if (it != g_fbp_filters.end()) { *out = it->second; return TOMO_OK; }
+    const std::vector<float> f = make_filter(nu, cutoff, multiplier);
+    float *dev = nullptr;
+    TOMO_HIP(hipMalloc((void **)&dev, f.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(dev, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice);  // synchronous, once
+    if (e != hipSuccess) {
+        (void)hipFree(dev);
+        return tomo_fail(TOMO_E_RUNTIME, "filter upload failed: %s", hipGetErrorString(e));
+    }
+    g_fbp_filters[key] = dev;
+    *out = dev;
+    return TOMO_OK;
+}
+
 }  // namespace
+
+void tomo_fbp_cache_release(int device)
+{
+    std::lock_guard<std::mutex> lk(g_fbp_mu);
+    tomo_device_guard guard(device);
+    for (auto it = g_fbp_plans.begin(); it != g_fbp_plans.end();) {
+        if (std::get<0>(it->first) == device) {
+            (void)hipfftDestroy(it->second.fwd);
+            (void)hipfftDestroy(it->second.inv);
+            it = g_fbp_plans.erase(it);
+        } else ++it;
+    }
+    for (auto it = g_fbp_filters.begin(); it != g_fbp_filters.end();) {
+        if (std::get<0>(it->first) == device) {
+            (void)hipFree(it->second);
+            it = g_fbp_filters.erase(it);
+        } else ++it;
+    }
+}
 
 extern "C" int tomo_fbp_filter(int device, float *data_dev, size_t rows, int nu, float cutoff, float multiplier,
                                void *stream)
@@ -69,35 +136,29 @@ extern "C" int tomo_fbp_filter(int device, float *data_dev, size_t rows, int nu,
     TOMO_REQUIRE(device >= 0 && data_dev != nullptr && nu >= 2 && cutoff > 0.0f, "bad FBP filter arguments");
     if (rows == 0) return TOMO_OK;
     TOMO_REQUIRE(rows <= 0x7fffffffULL, "too many projection rows for one hipFFT plan");
-    TOMO_HIP(hipSetDevice(device));
+    TOMO_ON_DEVICE(device);
     hipStream_t st = as_stream(stream);
     const int nh = nu / 2 + 1;
     const size_t spec_bytes = rows * (size_t)nh * sizeof(float2);
-    const size_t filt_bytes = ((size_t)nh * sizeof(float) + 255) / 256 * 256;
     void *base = nullptr;
-    int rc = tomo_arena_get(device, spec_bytes + filt_bytes, &base);
+    int rc = tomo_arena_get(device, st, ARENA_MAIN, spec_bytes, &base);
     if (rc != TOMO_OK) return rc;
     float2 *spec = (float2 *)base;
-    float *filt = (float *)((char *)base + spec_bytes);
-    const std::vector<float> f = make_filter(nu, cutoff, multiplier);
-    TOMO_HIP(hipMemcpyAsync(filt, f.data(), (size_t)nh * sizeof(float), hipMemcpyHostToDevice, st));
-    TOMO_HIP(hipStreamSynchronize(st));  // f is a stack-owned host buffer
-
-    hipfftHandle fwd = 0, inv = 0;
-    int n[1] = {nu};
-    TOMO_FFT(hipfftPlanMany(&fwd, 1, n, nullptr, 1, nu, nullptr, 1, nh, HIPFFT_R2C, (int)rows));
-    TOMO_FFT(hipfftPlanMany(&inv, 1, n, nullptr, 1, nh, nullptr, 1, nu, HIPFFT_C2R, (int)rows));
-    TOMO_FFT(hipfftSetStream(fwd, st));
-    TOMO_FFT(hipfftSetStream(inv, st));
-    TOMO_FFT(hipfftExecR2C(fwd, data_dev, (hipfftComplex *)spec));
+    std::lock_guard<std::mutex> lk(g_fbp_mu);  // a cached plan is bound to one stream at a time
+    const float *filt = nullptr;
+    rc = fbp_get_filter(device, nu, cutoff, multiplier, &filt);
+    if (rc != TOMO_OK) return rc;
+    fbp_plans p;
+    rc = fbp_get_plans(device, nu, rows, p);
+    if (rc != TOMO_OK) return rc;
+    TOMO_FFT(hipfftSetStream(p.fwd, st));
+    TOMO_FFT(hipfftSetStream(p.inv, st));
+    TOMO_FFT(hipfftExecR2C(p.fwd, data_dev, (hipfftComplex *)spec));
     size_t total = rows * (size_t)nh;
     size_t grid = (total + 255) / 256;
     if (grid > 4096) grid = 4096;
     apply_filter_kernel<<<(unsigned)grid, 256, 0, st>>>(spec, filt, rows, nh);
     TOMO_LAUNCH_CHECK();
-    TOMO_FFT(hipfftExecC2R(inv, (hipfftComplex *)spec, data_dev));
-    TOMO_HIP(hipStreamSynchronize(st));  // plans are destroyed below
-    (void)hipfftDestroy(fwd);
-    (void)hipfftDestroy(inv);
-    return TOMO_OK;
+    TOMO_FFT(hipfftExecC2R(p.inv, (hipfftComplex *)spec, data_dev));
+    return TOMO_OK;  // asynchronous on `st`: no host synchronisation
 }

@@ -516,7 +516,7 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
                  "bad Fourier reconstruction parameters");
     TOMO_REQUIRE(out_z >= 1 && out_z <= nz && center_size >= 0 && center_size <= 2 * n, "bad output / centre size");
     TOMO_REQUIRE(2L * n <= 32768, "detector too wide for the Fourier reconstruction grid");
-    TOMO_HIP(hipSetDevice(device));
+    TOMO_ON_DEVICE(device);
     hipStream_t st = as_stream(stream);
     int rc = TOMO_OK;
 
@@ -537,7 +537,7 @@ extern "C" int tomo_fourier_inv(int device, const float *data_dev, float *out_de
     {   // workspace: the per-device grow-only scratch arena (shared with the TV operators, released by tomo_release_scratch)
         const size_t total = al(bytes_buf) + al(bytes_spec) + al(bytes_datac) + al(bytes_g) + al(bytes_f) + al(bytes_tab);
         void *base = nullptr;
-        rc = tomo_arena_get(device, total, &base);
+        rc = tomo_arena_get(device, st, ARENA_MAIN, total, &base);
         if (rc != TOMO_OK) return rc;
         ws = (char *)base;
     }

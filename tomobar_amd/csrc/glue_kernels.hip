@@ -158,7 +158,7 @@ int reduce_host(const float *x, const float *y, size_t n, double *out, void *str
     TOMO_HIP(hipGetDevice(&dev));
     const int grid = ew_grid(n);
     void *buf = nullptr;
-    int rc = tomo_arena_get(dev + 1024, (size_t)EW_MAX_GRID * sizeof(double), &buf);  // small dedicated arena
+    int rc = tomo_arena_get(dev, as_stream(stream), ARENA_REDUCE, (size_t)EW_MAX_GRID * sizeof(double), &buf);
     if (rc != TOMO_OK) return rc;
     reduce_kernel<MODE><<<grid, EW_BLOCK, 0, as_stream(stream)>>>(x, y, n, (double *)buf);
     TOMO_LAUNCH_CHECK();

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <string>
 #include <type_traits>
 
 namespace {
@@ -50,6 +51,8 @@ struct BpArgs {
     float s0, s1, s2, s3;    // FISTA: l_inv, beta ; ADMM: tau, rho, (1-alpha), alpha
     int nonneg, relax_on;
     int ntx, nty, nzb;       // tiled variant: tile counts
+    int device;              // host side only: the context's device (made current around the launch)
+    std::string *path;       // host side only: receives the name of the kernel that ran
 };
 
 // No contraction here: these are the separate CuPy ufunc roundings of methodsIR_CuPy.py:463-475,545-557.
@@ -221,14 +224,20 @@ __global__ __launch_bounds__(256) void bp_tiled_kernel(BpArgs a)
 template <int EPI>
 int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
 {
+    TOMO_ON_DEVICE(a.device);
     tomo_prof_scope prof(PROF_BP, st, 1);
     // the brick kernel addresses a 16-slice sinogram slab with 32-bit element offsets
     const bool brick_ok = (long)a.na * a.nu < (1L << 27);
     if (g_variant_bp == 1 || (g_variant_bp == 0 && !brick_ok)) {
+        if (g_variant_bp == 0)
+            tomo_warn_once("bp_direct", "back projection: angles x detector >= 2^27 samples per slice, falling back to "
+                                        "the direct (no LDS) kernel (about 3.5x slower)");
+        if (a.path) *a.path = "direct(no LDS)";
         dim3 grid(ceil_div(a.n, 64), ceil_div(a.n, 4), ceil_div(a.nz, 4));
         if (lerp8) bp_direct_kernel<EPI, true><<<grid, 256, 0, st>>>(a);
         else bp_direct_kernel<EPI, false><<<grid, 256, 0, st>>>(a);
     } else if (g_variant_bp == 0) {
+        if (a.path) *a.path = "brick(32x16x16)";
         a.ntx = ceil_div(a.n, BB_TX);
         a.nty = ceil_div(a.n, BB_TY);
         a.nzb = ceil_div(a.nz, 4 * BB_ZQ);
@@ -237,6 +246,7 @@ int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
         if (lerp8) bp_brick_kernel<EPI, true><<<(unsigned)blocks, 256, 0, st>>>(a);
         else bp_brick_kernel<EPI, false><<<(unsigned)blocks, 256, 0, st>>>(a);
     } else {
+        if (a.path) *a.path = "tiled(64x8x16)";
         a.ntx = ceil_div(a.n, BP_TX);
         a.nty = ceil_div(a.n, BP_TY);
         a.nzb = ceil_div(a.nz, 4 * BP_ZQ);
@@ -348,7 +358,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
     TOMO_REQUIRE(subset < ctx->os, "subset %d out of range (OS_number %d)", subset, ctx->os);
     tomo_subset &s = (subset < 0 || ctx->os == 1) ? ctx->subsets[0] : ctx->subsets[1 + subset];
     if (s.size == 0) return TOMO_OK;
-    TOMO_HIP(hipSetDevice(ctx->device));
+    TOMO_ON_DEVICE(ctx->device);
     hipStream_t st = as_stream(stream);
     FpArgs a;
     a.vol = vol;
@@ -370,6 +380,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
     a.out = out; a.b = b; a.w = w; a.fidelity = fidelity; a.gathered = gathered;
     dim3 grid(ceil_div(ctx->nu, 256), s.size, ceil_div(ctx->nz, 4));
     tomo_prof_scope prof(PROF_FP, st, 1);
+    ctx->last_fp_path.clear();
     const bool l8 = (ctx->flags & TOMO_FLAG_LERP8) != 0;
     // tiled variant unless a class's LDS window would not fit (very wide angular spread on a very wide volume)
     bool tiled = (g_variant_fp != 1);
@@ -407,10 +418,20 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 const double cost_rows = (double)nut_w * ceil_div(nc, FP_A) * wp;
                 const bool pays = wide_env == 1 || cost_tiles >= 1.25 * cost_rows;
                 const int passes_w = ceil_div(wp, 1024);
+                // rows per chunk: 4 (or 2) double-buffered rows up to two column passes; detectors wider than 2048
+                // (3-5 passes, BASELINE configs[4] is 2560 wide) keep ONE tile (two barriers per chunk) of as many
+                // rows as fit in the 160 KiB of LDS next to the per-row window tables
                 int kc_w = 4;
-                size_t smem_w = (size_t)2 * kc_w * wp * 16 + (size_t)a.n * 8;
-                if (smem_w > 160 * 1024) { kc_w = 2; smem_w = (size_t)2 * kc_w * wp * 16 + (size_t)a.n * 8; }
-                if (!(pays && passes_w <= 2 && smem_w <= 160 * 1024)) continue;
+                const size_t tab_w = (size_t)a.n * 8;
+                size_t smem_w = (size_t)2 * kc_w * wp * 16 + tab_w;
+                if (passes_w <= 2) {
+                    if (smem_w > 160 * 1024) { kc_w = 2; smem_w = (size_t)2 * kc_w * wp * 16 + tab_w; }
+                } else {
+                    kc_w = passes_w == 3 ? 2 : 1;  // 3 rows (9 float4 in flight per thread) spill at 1024 threads
+                    while (kc_w > 1 && (size_t)kc_w * wp * 16 + tab_w > 160 * 1024) --kc_w;
+                    smem_w = (size_t)kc_w * wp * 16 + tab_w;
+                }
+                if (!(pays && passes_w <= 5 && smem_w <= 160 * 1024)) continue;
                 FpTiledArgs t;
                 t.src = d ? a.volT : a.vol;
                 t.tab = a.tab;
@@ -432,13 +453,20 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
             kern<<<(unsigned)blocks_w, 1024, smem_w, st>>>(t);                                                         \
         };                                                                                                             \
         if (passes_w == 1) launch(fp_tiled_kernel<L8, RES, 1, 4, true, 1024>);                                         \
-        else if (kc_w == 4) launch(fp_tiled_kernel<L8, RES, 2, 8, true, 1024>);                                        \
-        else launch(fp_tiled_kernel<L8, RES, 2, 4, true, 1024>);                                                       \
+        else if (passes_w == 2 && kc_w == 4) launch(fp_tiled_kernel<L8, RES, 2, 8, true, 1024>);                       \
+        else if (passes_w == 2) launch(fp_tiled_kernel<L8, RES, 2, 4, true, 1024>);                                    \
+        else if (passes_w == 3 && kc_w == 2) launch(fp_tiled_kernel<L8, RES, 3, 6, false, 1024>);                      \
+        else if (passes_w == 3) launch(fp_tiled_kernel<L8, RES, 3, 3, false, 1024>);                                   \
+        else if (passes_w == 4) launch(fp_tiled_kernel<L8, RES, 4, 4, false, 1024>);                                   \
+        else launch(fp_tiled_kernel<L8, RES, 5, 5, false, 1024>);                                                      \
     } while (0)
                 if (b) { if (l8) FP_WIDE_LAUNCH(true, true); else FP_WIDE_LAUNCH(false, true); }
                 else   { if (l8) FP_WIDE_LAUNCH(true, false); else FP_WIDE_LAUNCH(false, false); }
 #undef FP_WIDE_LAUNCH
                 TOMO_LAUNCH_CHECK();
+                ctx->last_fp_path += (d ? "x:" : "y:");
+                ctx->last_fp_path += "whole-row(1024 threads, " + std::to_string(passes_w) + " passes, " +
+                                     std::to_string(kc_w) + " rows/chunk) ";
                 done[2 * d] = done[2 * d + 1] = true;
             }
         }
@@ -479,6 +507,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                     else   { if (l8) FP_SYNC_LAUNCH(true, false); else FP_SYNC_LAUNCH(false, false); }
 #undef FP_SYNC_LAUNCH
                     TOMO_LAUNCH_CHECK();
+                    ctx->last_fp_path += "class" + std::to_string(c) + ":tiled-sync(window " + std::to_string(t.wpitch) + ") ";
                     order_off += nc;
                     continue;
                 }
@@ -494,11 +523,16 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 else   { if (l8) FP_TILED_LAUNCH(true, false); else FP_TILED_LAUNCH(false, false); }
 #undef FP_TILED_LAUNCH
                 TOMO_LAUNCH_CHECK();
+                ctx->last_fp_path += "class" + std::to_string(c) + ":tiled-pipelined(256 threads, " + std::to_string(passes) +
+                                     " passes) ";
             }
             order_off += nc;
         }
         return TOMO_OK;
     }
+    ctx->last_fp_path = "march(no LDS)";
+    if (g_variant_fp != 1) tomo_warn_once("fp_march", "forward projection: a staged row window exceeds 64 KiB of LDS, "
+                                          "falling back to the un-tiled march kernel (about 4x slower)");
     if (b) {
         if (l8) fp_march_kernel<true, true><<<grid, 256, 0, st>>>(a);
         else fp_march_kernel<false, true><<<grid, 256, 0, st>>>(a);
@@ -516,8 +550,9 @@ int bp_prepare(tomo_ctx *ctx, int subset, const float *sino, BpArgs &a)
     TOMO_REQUIRE(subset < ctx->os, "subset %d out of range (OS_number %d)", subset, ctx->os);
     const tomo_subset &s = (subset < 0 || ctx->os == 1) ? ctx->subsets[0] : ctx->subsets[1 + subset];
     TOMO_REQUIRE(sino != nullptr || s.size == 0, "NULL sinogram pointer");
-    TOMO_HIP(hipSetDevice(ctx->device));
     a = BpArgs();
+    a.device = ctx->device;
+    a.path = &ctx->last_bp_path;
     a.sino = sino;
     a.tab = ctx->dev_table + s.table_offset;
     a.nz = ctx->nz; a.n = ctx->n; a.nu = ctx->nu; a.na = s.size;

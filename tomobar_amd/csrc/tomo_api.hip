@@ -94,7 +94,7 @@ extern "C" int tomo_ctx_create(int device, int nz, int n, int nu, int na, const 
     int rc = tomo_device_count(&ndev);
     if (rc != TOMO_OK) return rc;
     TOMO_REQUIRE(device < ndev, "device index %d out of range (%d devices)", device, ndev);
-    TOMO_HIP(hipSetDevice(device));
+    TOMO_ON_DEVICE(device);
 
     tomo_ctx *ctx = new (std::nothrow) tomo_ctx();
     if (!ctx) return tomo_fail(TOMO_E_NOMEM, "out of host memory");
@@ -167,7 +167,7 @@ extern "C" int tomo_ctx_create(int device, int nz, int n, int nu, int na, const 
 extern "C" int tomo_ctx_destroy(tomo_ctx *ctx)
 {
     if (!ctx) return TOMO_OK;
-    (void)hipSetDevice(ctx->device);
+    tomo_device_guard guard(ctx->device);
     if (ctx->dev_table) (void)hipFree(ctx->dev_table);
     if (ctx->dev_fp_order) (void)hipFree(ctx->dev_fp_order);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -179,13 +179,29 @@ extern "C" int tomo_ctx_release_scratch(tomo_ctx *ctx)
 {
     TOMO_REQUIRE(ctx != nullptr, "ctx is NULL");
     if (ctx->scratch) {
-        TOMO_HIP(hipSetDevice(ctx->device));
+        TOMO_ON_DEVICE(ctx->device);
         TOMO_HIP(hipDeviceSynchronize());
         TOMO_HIP(hipFree(ctx->scratch));
         ctx->scratch = nullptr;
         ctx->scratch_bytes = 0;
     }
     return TOMO_OK;
+}
+
+void tomo_warn_once(const char *key, const char *msg)
+{
+    static std::mutex mu;
+    static std::map<std::string, bool> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    if (seen[key]) return;
+    seen[key] = true;
+    fprintf(stderr, "libtomo_mi355x warning: %s\n", msg);
+}
+
+extern "C" const char *tomo_ctx_kernel_path(const tomo_ctx *ctx, const char *op)
+{
+    if (!ctx || !op) return "";
+    return std::string(op) == "bp" ? ctx->last_bp_path.c_str() : ctx->last_fp_path.c_str();
 }
 
 extern "C" int tomo_ctx_os_number(const tomo_ctx *ctx) { return ctx ? ctx->os : -1; }
@@ -221,18 +237,28 @@ extern "C" int tomo_ctx_angle_table(const tomo_ctx *ctx, int subset, tomo_angle_
     return TOMO_OK;
 }
 
-// ---- per-device grow-only arena for the TV drivers
+// ---- grow-only scratch arenas, one per (device, stream, slot): two streams of one device never alias scratch, and
+//      growing an arena waits for THAT stream only
 struct arena_t { void *ptr = nullptr; size_t bytes = 0; };
+struct arena_key {
+    int device; hipStream_t stream; int slot;
+    bool operator<(const arena_key &o) const
+    {
+        if (device != o.device) return device < o.device;
+        if (stream != o.stream) return stream < o.stream;
+        return slot < o.slot;
+    }
+};
 static std::mutex g_arena_mu;
-static std::map<int, arena_t> g_arenas;
+static std::map<arena_key, arena_t> g_arenas;
 
-int tomo_arena_get(int device, size_t bytes, void **out)
+int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void **out)
 {
     std::lock_guard<std::mutex> lk(g_arena_mu);
-    arena_t &a = g_arenas[device];
+    arena_t &a = g_arenas[arena_key{device, stream, slot}];
     if (a.bytes < bytes) {
         if (a.ptr) {
-            TOMO_HIP(hipDeviceSynchronize());
+            TOMO_HIP(hipStreamSynchronize(stream));  // the only user of this arena
             TOMO_HIP(hipFree(a.ptr));
             a.ptr = nullptr;
             a.bytes = 0;
@@ -247,13 +273,22 @@ int tomo_arena_get(int device, size_t bytes, void **out)
 extern "C" int tomo_release_scratch(int device)
 {
     tomo_fourier_cache_release(device);
+    tomo_fbp_cache_release(device);
     std::lock_guard<std::mutex> lk(g_arena_mu);
-    auto it = g_arenas.find(device);
-    if (it != g_arenas.end() && it->second.ptr) {
-        TOMO_HIP(hipSetDevice(device));
-        TOMO_HIP(hipDeviceSynchronize());
-        TOMO_HIP(hipFree(it->second.ptr));
-        g_arenas.erase(it);
+    bool any = false;
+    for (auto it = g_arenas.begin(); it != g_arenas.end();) {
+        if (it->first.device == device && it->second.ptr) {
+            if (!any) {
+                TOMO_ON_DEVICE(device);
+                TOMO_HIP(hipDeviceSynchronize());
+                any = true;
+            }
+            tomo_device_guard g(device);
+            TOMO_HIP(hipFree(it->second.ptr));
+            it = g_arenas.erase(it);
+        } else {
+            ++it;
+        }
     }
     return TOMO_OK;
 }

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <string>
 #include <vector>
 
 #include "tomo_mi355x.h"
@@ -60,13 +61,38 @@ struct tomo_ctx {
     int *dev_fp_order = nullptr;
     void *scratch = nullptr;                  // grow-only (FP: in-plane transposed volume)
     size_t scratch_bytes = 0;
+    std::string last_fp_path, last_bp_path;   // which kernels the last FP / BP call ran (tomo_ctx_kernel_path)
 };
+
+// one message per process and key on stderr (a slow fallback kernel was taken)
+void tomo_warn_once(const char *key, const char *msg);
+
+// Makes `device` current for the lifetime of the object and restores the caller's current device afterwards: entry
+// points never leave the calling thread on another device (torch's current device stays what the caller set).
+struct tomo_device_guard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit tomo_device_guard(int device)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+        else if (err == hipSuccess) prev = -1;  // nothing to restore
+    }
+    ~tomo_device_guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    tomo_device_guard(const tomo_device_guard &) = delete;
+    tomo_device_guard &operator=(const tomo_device_guard &) = delete;
+};
+#define TOMO_ON_DEVICE(dev)                 \
+    tomo_device_guard device_guard_(dev);   \
+    TOMO_HIP(device_guard_.err)
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-// grow-only per-device arena used by the TV drivers (tomo_release_scratch frees it)
-int tomo_arena_get(int device, size_t bytes, void **out);
+// grow-only scratch arena per (device, stream, slot) (tomo_release_scratch frees a device's arenas)
+enum { ARENA_MAIN = 0, ARENA_REDUCE = 1 };
+int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void **out);
 void tomo_fourier_cache_release(int device);  // cached hipFFT plans of fourier_inv.hip
+void tomo_fbp_cache_release(int device);      // cached hipFFT plans / filter tables of fbp_filter.hip
 
 // kernel-variant switches (tomo_set_variant)
 extern int g_variant_bp, g_variant_fp, g_variant_pdtv, g_variant_roftv;

@@ -494,7 +494,7 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
     if (nd == 2) dz = 1;
     TOMO_REQUIRE(dx > 0 && dy > 0 && dz > 0 && iters >= 0, "bad PD_TV dimensions / iterations");
     TOMO_REQUIRE(in_dev && out_dev, "NULL data pointer");
-    TOMO_HIP(hipSetDevice(device));
+    TOMO_ON_DEVICE(device);
     hipStream_t st = as_stream(stream);
     const size_t nvox = (size_t)dx * dy * dz;
     if (iters == 0) {
@@ -502,7 +502,7 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
         return TOMO_OK;
     }
     void *base = nullptr;
-    int rc = tomo_arena_get(device, tomo_pdtv_scratch_bytes(dx, dy, dz, nd, half), &base);
+    int rc = tomo_arena_get(device, st, ARENA_MAIN, tomo_pdtv_scratch_bytes(dx, dy, dz, nd, half), &base);
     if (rc != TOMO_OK) return rc;
     const size_t ub = align_up(nvox * sizeof(float), 256);
     const size_t pb = align_up(nvox * (half ? 2 : 4), 256);
@@ -556,7 +556,7 @@ extern "C" int tomo_pdtv_iter_slab(int device, const float *in_dev, const float 
                                    int methodTV, int nonneg, int half, void *stream)
 {
     TOMO_REQUIRE(device >= 0 && dx > 0 && dy > 0 && nz_local > 0, "bad slab arguments");
-    TOMO_HIP(hipSetDevice(device));
+    TOMO_ON_DEVICE(device);
     PdArgs a;
     a.in = in_dev; a.u_in = u_in_dev; a.u_out = u_out_dev;
     for (int c = 0; c < 3; ++c) { a.p_in[c] = p_in_dev[c]; a.p_out[c] = p_out_dev[c]; }
@@ -590,7 +590,7 @@ extern "C" int tomo_pdtv_pair_slab_range(int device, const float *in_dev, const 
     if (z_begin == z_end) return TOMO_OK;
     TOMO_REQUIRE((lo_planes == 0 || lo_planes == 2) && (hi_planes == 0 || hi_planes == 2),
                  "the two-iteration slab kernel needs 0 or 2 ghost planes on either side");
-    TOMO_HIP(hipSetDevice(device));
+    TOMO_ON_DEVICE(device);
     PdArgs a;
     a.in = in_dev; a.u_in = u_in_dev; a.u_out = u_out_dev;
     for (int c = 0; c < 3; ++c) { a.p_in[c] = p_in_dev[c]; a.p_out[c] = p_out_dev[c]; }
@@ -615,7 +615,7 @@ extern "C" int tomo_roftv(int device, const float *in_dev, float *out_dev, int d
     TOMO_REQUIRE(dx >= 2 && dy >= 2 && (nd == 2 || dz >= 2) && iters >= 0,
                  "ROF_TV needs every dimension >= 2 (reflecting boundary)");
     TOMO_REQUIRE(in_dev && out_dev, "NULL data pointer");
-    TOMO_HIP(hipSetDevice(device));
+    TOMO_ON_DEVICE(device);
     hipStream_t st = as_stream(stream);
     const size_t nvox = (size_t)dx * dy * dz;
     if (iters == 0) {
@@ -623,7 +623,7 @@ extern "C" int tomo_roftv(int device, const float *in_dev, float *out_dev, int d
         return TOMO_OK;
     }
     void *base = nullptr;
-    int rc = tomo_arena_get(device, tomo_roftv_scratch_bytes(dx, dy, dz, nd), &base);
+    int rc = tomo_arena_get(device, st, ARENA_MAIN, tomo_roftv_scratch_bytes(dx, dy, dz, nd), &base);
     if (rc != TOMO_OK) return rc;
     const size_t ub = align_up(nvox * sizeof(float), 256);
     float *U[2] = {(float *)base, (float *)((char *)base + ub)};
@@ -661,7 +661,7 @@ extern "C" int tomo_roftv_iter_slab_range(int device, const float *in_dev, const
     if (z_begin == z_end) return TOMO_OK;
     TOMO_REQUIRE((lo_planes == 0 || lo_planes == 2) && (hi_planes == 0 || hi_planes == 1),
                  "ROF slab needs 0 or 2 ghost planes below and 0 or 1 above");
-    TOMO_HIP(hipSetDevice(device));
+    TOMO_ON_DEVICE(device);
     RofArgs a;
     a.in = in_dev; a.u_in = u_in_dev; a.u_out = u_out_dev;
     a.dx = dx; a.dy = dy;

@@ -60,11 +60,21 @@ class RecToolsDIRCuPy:
 
     def FORWPROJ(self, data, **kwargs):
         """Forward projection of a volume ``[Z, Y, X]`` -> ``[detY, angles, detX]`` (methodsDIR_CuPy.py:70-90); in 2D
-        geometry an image ``[Y, X]`` -> ``[angles, detX]`` (methodsDIR.py:71-96)."""
+        geometry an image ``[Y, X]`` -> ``[angles, detX]`` (methodsDIR.py:71-96).
+
+        Keyword Args: ``data_axes_labels_order`` -- axis order of the OUTPUT; the reference applies
+        ``_data_dims_swapper(projected, value, ["detY", "angles", "detX"])`` (:84-88), so does this (the swapped
+        result is returned C-contiguous)."""
         data = ops.to_device(data, self.Atools.device_index)
-        if self.is2d and data.dim() == 2:
-            return self.Atools._forwprojCuPy(data.unsqueeze(0)).squeeze(0)
-        return self.Atools._forwprojCuPy(data)
+        flat = self.is2d and data.dim() == 2
+        projected = self.Atools._forwprojCuPy(data.unsqueeze(0) if flat else data)
+        if flat:
+            projected = projected.squeeze(0)
+        labels = kwargs.get("data_axes_labels_order")
+        if labels is not None:
+            projected = ops.contiguous(_data_dims_swapper(projected, labels,
+                                                          ["angles", "detX"] if flat else ["detY", "angles", "detX"]))
+        return projected
 
     def BACKPROJ(self, data, **kwargs):
         """Back projection of ``[detY, angles, detX]`` data (methodsDIR_CuPy.py:92-112).  The input is made

@@ -35,6 +35,11 @@ def stream_ptr(t: torch.Tensor):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def _on(t: torch.Tensor):
+    """Context making the tensor's device current for a launch (the launch stream belongs to that device)."""
+    return torch.cuda.device(t.device)
+
+
 def ptr(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
@@ -68,35 +73,43 @@ def contiguous(t: torch.Tensor) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- element-wise / reductions
 def momentum(x, x_old, x_t, beta):
-    L.check(L.lib().tomo_momentum(ptr(x), ptr(x_old), ptr(x_t), float(beta), x.numel(), stream_ptr(x)))
+    with _on(x):
+        L.check(L.lib().tomo_momentum(ptr(x), ptr(x_old), ptr(x_t), float(beta), x.numel(), stream_ptr(x)))
 
 
 def admm_dual(u, z, x):
-    L.check(L.lib().tomo_admm_dual(ptr(u), ptr(z), ptr(x), u.numel(), stream_ptr(u)))
+    with _on(u):
+        L.check(L.lib().tomo_admm_dual(ptr(u), ptr(z), ptr(x), u.numel(), stream_ptr(u)))
 
 
 def axpby(a, x, b, y):
-    L.check(L.lib().tomo_axpby(float(a), ptr(x), float(b), ptr(y), y.numel(), stream_ptr(y)))
+    with _on(y):
+        L.check(L.lib().tomo_axpby(float(a), ptr(x), float(b), ptr(y), y.numel(), stream_ptr(y)))
 
 
 def scale(a, x, y):
-    L.check(L.lib().tomo_scale(float(a), ptr(x), ptr(y), y.numel(), stream_ptr(y)))
+    with _on(y):
+        L.check(L.lib().tomo_scale(float(a), ptr(x), ptr(y), y.numel(), stream_ptr(y)))
 
 
 def clamp_min(x, lo=0.0):
-    L.check(L.lib().tomo_clamp_min(ptr(x), float(lo), x.numel(), stream_ptr(x)))
+    with _on(x):
+        L.check(L.lib().tomo_clamp_min(ptr(x), float(lo), x.numel(), stream_ptr(x)))
 
 
 def mul(x, y):
-    L.check(L.lib().tomo_mul(ptr(x), ptr(y), y.numel(), stream_ptr(y)))
+    with _on(y):
+        L.check(L.lib().tomo_mul(ptr(x), ptr(y), y.numel(), stream_ptr(y)))
 
 
 def recip_safe(x, y):
-    L.check(L.lib().tomo_recip_safe(ptr(x), ptr(y), y.numel(), stream_ptr(y)))
+    with _on(y):
+        L.check(L.lib().tomo_recip_safe(ptr(x), ptr(y), y.numel(), stream_ptr(y)))
 
 
 def fill(x, value):
-    L.check(L.lib().tomo_fill(ptr(x), float(value), x.numel(), stream_ptr(x)))
+    with _on(x):
+        L.check(L.lib().tomo_fill(ptr(x), float(value), x.numel(), stream_ptr(x)))
 
 
 def norm2(x) -> float:
@@ -131,20 +144,23 @@ def pwls_weights(b, slab=None):
 def pad_edge(b, pad):
     nz, na, nu0 = b.shape
     out = torch.empty((nz, na, nu0 + 2 * pad), dtype=torch.float32, device=b.device)
-    L.check(L.lib().tomo_pad_edge(ptr(b), ptr(out), nz * na, nu0, pad, stream_ptr(b)))
+    with _on(b):
+        L.check(L.lib().tomo_pad_edge(ptr(b), ptr(out), nz * na, nu0, pad, stream_ptr(b)))
     return out
 
 
 def crop_center(vol, m):
     nz, n, _ = vol.shape
     out = torch.empty((nz, m, m), dtype=torch.float32, device=vol.device)
-    L.check(L.lib().tomo_crop_center(ptr(vol), ptr(out), nz, n, m, stream_ptr(vol)))
+    with _on(vol):
+        L.check(L.lib().tomo_crop_center(ptr(vol), ptr(out), nz, n, m, stream_ptr(vol)))
     return out
 
 
 def circ_mask_(vol, radius):
     nz, n, _ = vol.shape
-    L.check(L.lib().tomo_circ_mask(ptr(vol), nz, n, float(radius), stream_ptr(vol)))
+    with _on(vol):
+        L.check(L.lib().tomo_circ_mask(ptr(vol), nz, n, float(radius), stream_ptr(vol)))
     return vol
 
 

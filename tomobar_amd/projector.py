@@ -230,6 +230,10 @@ class HipTools3D:
         L.check(L.lib().tomo_ctx_angle_table(self._ctx, self._sub(os_index), tab, max(n, 1)))
         return tab, n
 
+    def kernel_path(self, op: str = "fp") -> str:
+        """Which kernel form the last forward ("fp") / back ("bp") projection of this object took (diagnostics)."""
+        return L.lib().tomo_ctx_kernel_path(self._ctx, op.encode()).decode()
+
     def release_scratch(self):
         L.check(L.lib().tomo_ctx_release_scratch(self._ctx))
 

@@ -28,14 +28,40 @@ import torch
 
 
 def slab_bounds(nz_total: int, world: int, rank: int):
-    """Contiguous slab [z0, z1) of rank `rank`: ceil(nz/world) slices each, the last slabs may be shorter / empty."""
-    per = -(-nz_total // world)
-    z0 = min(rank * per, nz_total)
-    return z0, min(z0 + per, nz_total)
+    """Contiguous slab [z0, z1) of rank `rank`, balanced: the first ``nz_total % world`` ranks hold one slice more
+    than the others (floor / ceil split), so no rank is left short or empty while another holds a full share."""
+    base, extra = divmod(int(nz_total), int(world))
+    z0 = rank * base + min(rank, extra)
+    return z0, z0 + base + (1 if rank < extra else 0)
+
+
+def check_slab_split(nz_total: int, world: int, min_slices: int = 2):
+    """Every rank evaluates this identical test BEFORE any exchange is posted, so a volume that is too short for the
+    requested number of slabs raises on all ranks at once (a rank raising alone would leave its neighbours blocked in
+    their send/recv).  3D TV needs at least two slices per slab (two-plane ghosts)."""
+    if world > 1 and nz_total < min_slices * world:
+        raise ValueError(f"{nz_total} slices cannot be split into {world} z-slabs of at least {min_slices} slices; "
+                         f"use at most {max(nz_total // min_slices, 1)} ranks")
+
+
+class _StagedRequest:
+    """Completion handle of a host-staged transfer (gloo moving device tensors): wait() finishes the CPU transfer and,
+    for a receive, copies the plane into the device tensor on the current stream."""
+
+    def __init__(self, req, host, dev=None):
+        self.req, self.host, self.dev = req, host, dev
+
+    def wait(self):
+        self.req.wait()
+        if self.dev is not None:
+            self.dev.copy_(self.host, non_blocking=False)
 
 
 class SlabComm:
-    """Neighbour exchange and scalar reductions for one rank of a z-slab decomposition."""
+    """Neighbour exchange and scalar reductions for one rank of a z-slab decomposition.
+
+    Backend "nccl" (RCCL over xGMI) moves device tensors directly.  With "gloo" device tensors are staged through host
+    memory (functional path for the CPU tests and for several ranks sharing one GPU; not a performance path)."""
 
     def __init__(self, rank: int, world: int, device=None, group=None):
         import torch.distributed as dist
@@ -45,48 +71,84 @@ class SlabComm:
         self.group = group
         self.has_lo = self.rank > 0
         self.has_hi = self.rank < self.world - 1
+        self.backend = dist.get_backend(group) if dist.is_initialized() else "gloo"
+        self.staged = self.backend != "nccl"   # tensors handed to the backend must live on the host
+        self._validated = set()
+
+    def _scalar_device(self):
+        return None if self.staged else self.device
 
     # ---- scalars
     def allreduce_sum(self, value: float) -> float:
-        t = torch.tensor([value], dtype=torch.float64, device=self.device)
+        t = torch.tensor([value], dtype=torch.float64, device=self._scalar_device())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return float(t.item())
 
     def allreduce_max(self, value: float) -> float:
-        t = torch.tensor([value], dtype=torch.float64, device=self.device)
+        t = torch.tensor([value], dtype=torch.float64, device=self._scalar_device())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
+    def allgather_int(self, value: int):
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self._scalar_device())
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.group)
+        return [int(o.item()) for o in out]
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+    def validate_slabs(self, nz_local: int, min_slices: int = 2):
+        """Collective check (once per local slab height): every rank learns every slab's height and ALL ranks raise
+        together if one of them is too short for the ghost planes -- never a lone rank, which would strand its
+        neighbours inside a send/recv."""
+        key = (int(nz_local), int(min_slices))
+        if self.world == 1 or key in self._validated:
+            return
+        heights = self.allgather_int(nz_local)
+        self._validated.add(key)
+        short = [r for r, h in enumerate(heights) if h < min_slices]
+        if short:
+            raise ValueError(f"z-slabs of ranks {short} hold fewer than {min_slices} slices (heights {heights}): "
+                             "3D TV needs two-plane ghosts; use fewer ranks or balance the split with slab_bounds()")
+
     # ---- halo exchange
+    def _post(self, send_down, recv_down, send_up, recv_up):
+        """Post every send / receive of one exchange as ONE batch; returns completion handles."""
+        P2POp = self.dist.P2POp
+        plan = []
+        if self.has_lo:
+            plan += [(self.dist.isend, t, self.rank - 1) for t in send_down]
+            plan += [(self.dist.irecv, t, self.rank - 1) for t in recv_down]
+        if self.has_hi:
+            plan += [(self.dist.isend, t, self.rank + 1) for t in send_up]
+            plan += [(self.dist.irecv, t, self.rank + 1) for t in recv_up]
+        if not plan:
+            return []
+        if not (self.staged and any(t.is_cuda for _, t, _ in plan)):
+            return list(self.dist.batch_isend_irecv([P2POp(fn, t, peer, self.group) for fn, t, peer in plan]))
+        # host staging: the device->host copies of the planes to send are synchronous with the current stream, i.e.
+        # ordered after the kernels that produced them
+        ops, hosts = [], []
+        for fn, t, peer in plan:
+            h = t.cpu() if fn is self.dist.isend else torch.empty(t.shape, dtype=t.dtype)
+            hosts.append((h, t if fn is self.dist.irecv else None))
+            ops.append(P2POp(fn, h, peer, self.group))
+        reqs = self.dist.batch_isend_irecv(ops)
+        return [_StagedRequest(r, h, d) for r, (h, d) in zip(reqs, hosts)]
+
     def exchange(self, send_down: List[torch.Tensor], recv_down: List[torch.Tensor],
                  send_up: List[torch.Tensor], recv_up: List[torch.Tensor]):
         """send_down/recv_down talk to rank-1, send_up/recv_up to rank+1.  All planes are contiguous views; the k-th
         tensor sent up by rank r lands in the k-th tensor of rank r+1's recv_down (and likewise downwards)."""
-        ops = []
-        P2POp = self.dist.P2POp
-        if self.has_lo:
-            ops += [P2POp(self.dist.isend, t, self.rank - 1, self.group) for t in send_down]
-            ops += [P2POp(self.dist.irecv, t, self.rank - 1, self.group) for t in recv_down]
-        if self.has_hi:
-            ops += [P2POp(self.dist.isend, t, self.rank + 1, self.group) for t in send_up]
-            ops += [P2POp(self.dist.irecv, t, self.rank + 1, self.group) for t in recv_up]
-        if ops:
-            for req in self.dist.batch_isend_irecv(ops):
-                req.wait()
+        for req in self._post(send_down, recv_down, send_up, recv_up):
+            req.wait()
 
     def exchange_start(self, send_down, recv_down, send_up, recv_up):
         """Asynchronous form of `exchange`: returns the requests.  With the nccl (RCCL) backend the transfers are ordered
         after the work already queued on the current stream and run on RCCL's own stream, so kernels launched after this
         call overlap with them; `exchange_wait` makes the current stream wait for their completion."""
-        ops = []
-        P2POp = self.dist.P2POp
-        if self.has_lo:
-            ops += [P2POp(self.dist.isend, t, self.rank - 1, self.group) for t in send_down]
-            ops += [P2POp(self.dist.irecv, t, self.rank - 1, self.group) for t in recv_down]
-        if self.has_hi:
-            ops += [P2POp(self.dist.isend, t, self.rank + 1, self.group) for t in send_up]
-            ops += [P2POp(self.dist.irecv, t, self.rank + 1, self.group) for t in recv_up]
-        return self.dist.batch_isend_irecv(ops) if ops else []
+        return self._post(send_down, recv_down, send_up, recv_up)
 
     @staticmethod
     def exchange_wait(reqs):
@@ -249,6 +311,7 @@ def pd_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, m
     sigma = np.float32(1.0 / (lipschitz_const * tau))
     theta = np.float32(1.0)
     lt = np.float32(tau / regularisation_parameter)
+    comm.validate_slabs(data.shape[0])
     st = PdSlab(data, comm.has_lo, comm.has_hi, half_precision, pair_fn or _hip_pd_pair, step_fn or _hip_pd_step)
     comm.exchange(st.initial_send_down(), st.initial_recv_down(), st.initial_send_up(), st.initial_recv_up())
     it = 0
@@ -348,8 +411,7 @@ def _hip_rof_step(inp, u_in, u_out, dx, dy, nzl, lo, hi, lam, tau, half, zr=None
 
 def rof_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, time_marching_parameter,
                 half_precision=False, step_fn: Optional[Callable] = None, out=None, overlap: bool = True):
-    if data.shape[0] < 2 and (comm.has_lo or comm.has_hi):
-        raise ValueError("ROF_TV slabs must hold at least two slices")
+    comm.validate_slabs(data.shape[0])
     st = RofSlab(data, comm.has_lo, comm.has_hi, half_precision, step_fn or _hip_rof_step)
     lam, tau = np.float32(regularisation_parameter), np.float32(time_marching_parameter)
     comm.exchange(st.send_down(0), st.recv_down(0), st.send_up(0), st.recv_up(0))
