@@ -68,6 +68,23 @@ def test_full_size_tv_on_z_invariant_volume(oracle, shape):
     assert torch.equal(got3, want2.view(1, dy, dx).expand_as(got3)), float((got3 - want2.view(1, dy, dx)).abs().max())
 
 
+@pytest.mark.default_arithmetic
+def test_full_size_tv_shipped_arithmetic(oracle):
+    """1024^3 with the TV kernels as shipped (relaxed arithmetic): the z-invariance property within the tolerance."""
+    from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
+    nz, dy, dx = 1024, 1024, 1024
+    rng = np.random.default_rng(1)
+    base = (rng.random((dy, dx), dtype=np.float32) * 0.3 + (np.indices((dy, dx))[1] > dx // 2)).astype(np.float32)
+    vol = torch.from_numpy(base).cuda().unsqueeze(0).expand(nz, dy, dx).contiguous()
+    for fn, want2 in ((lambda: PD_TV_cupy(vol, 0.04, 30, 0, 1, 12.0, 0, False), oracle.pd_tv(base, 0.04, 30, 0, 1, 12.0, False)),
+                      (lambda: ROF_TV_cupy(vol, 0.04, 30, 0.005, 0, False), oracle.rof_tv(base, 0.04, 30, 0.005, False))):
+        got3 = fn()
+        w = torch.from_numpy(want2).cuda().view(1, dy, dx)
+        err = float(torch.linalg.vector_norm((got3 - w).double()) / (torch.linalg.vector_norm(w.double()) * nz ** 0.5))
+        assert err < 1e-5, err
+        del got3
+
+
 def test_config3_shape_projector_pair_against_oracle(oracle):
     """BASELINE configs[3] geometry (2048^2 slices, 1500 angles, no subsets; a 70-slice piece of a GPU's z-slab): same
     power-of-two slice scaling argument.  Exercises the two-tile detector, windows wider than 1024 columns and a ragged

@@ -33,13 +33,6 @@ def ops():
     return _ops
 
 
-@pytest.fixture(autouse=True)
-def _reset_variants(ops):
-    yield
-    for k in ("bp", "fp", "pdtv", "roftv"):
-        ops.set_variant(k, 0)
-
-
 # ------------------------------------------------------------------------------------------ projector pair
 GEOMS = [
     # nz, n, nu, na, cor, os
@@ -193,10 +186,11 @@ def test_fused_residual_and_gradient_steps(oracle, ops):
 
 # ------------------------------------------------------------------------------------------ TV operators
 TV_SHAPES = [(6, 9, 13), (1, 20, 17), (12, 1, 70), (10, 11, 1), (8, 8, 8), (3, 5, 131), (24, 19), (20, 70, 150)]
+PD_EXACT_VARIANTS = [2, 1, 10]   # bit-identical to the oracle; 0 (default), 11: relaxed arithmetic (tolerance)
 
 
 @pytest.mark.parametrize("shape", TV_SHAPES)
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", PD_EXACT_VARIANTS)
 def test_pdtv_vs_oracle(oracle, ops, shape, variant):
     from tomobar_amd.regularisersCuPy import PD_TV_cupy
     ops.set_variant("pdtv", variant)
@@ -213,8 +207,44 @@ def test_pdtv_vs_oracle(oracle, ops, shape, variant):
                 assert np.array_equal(got, want), (shape, variant, half, mtv, nn, np.abs(got - want).max())
 
 
+@pytest.mark.parametrize("shape", [(9, 40, 70), (20, 70, 150), (5, 33, 131)])
+@pytest.mark.parametrize("variant", [0, 3, 11])
+def test_pdtv_relaxed_arithmetic_vs_oracle(oracle, ops, shape, variant):
+    """The relaxed-arithmetic builds (the shipped default and the tile kernel: v_rsq / v_rcp, hoisted 1/(1+lt)) stay
+    within the north-star tolerance of the oracle after 60 iterations."""
+    from tomobar_amd.regularisersCuPy import PD_TV_cupy
+    ops.set_variant("pdtv", variant)
+    rng = np.random.default_rng(6)
+    x = (rng.random(shape) * 0.3 + (np.indices(shape)[-1] > shape[-1] // 2)).astype(np.float32)
+    for half in (False, True):
+        for mtv in (0, 1):
+            want = oracle.pd_tv(x, 0.04, 60, mtv, 1, 12.0, half)
+            got = host(PD_TV_cupy(dev(x), 0.04, 60, mtv, 1, 12.0, 0, half))
+            if half and variant == 0:   # shipped build: binary16 duals run the exact arithmetic
+                assert np.array_equal(got, want)
+            assert rel(got, want) < (1e-5 if not half else 2e-4), (shape, variant, half, mtv, rel(got, want))
+
+
+@pytest.mark.parametrize("shape", TV_SHAPES + [(9, 40, 70)])
+def test_roftv_relaxed_arithmetic_vs_oracle(oracle, ops, shape):
+    """The shipped ROF_TV (float32 sum + v_rsq_f32 in the D normalisation) vs the oracle after 60 iterations.  The input
+    is noise-dominated on purpose: ROF's min-mod limiter (rudin_osher...cu:51-55) is discontinuous where a forward and a
+    backward difference change sign against each other, so one-ulp differences can flip a limiter and show up at the
+    1e-5 level on such data (the reference's own two builds, with and without FMA contraction, differ the same way);
+    the bound here is 1e-4, the fixtures of the reference's kernels and the reconstruction fixtures hold 1e-5
+    (test_shipped_tv_arithmetic_against_reference_fixtures, tests/test_gpu_recon.py)."""
+    from tomobar_amd.regularisersCuPy import ROF_TV_cupy
+    ops.set_variant("roftv", 0)
+    rng = np.random.default_rng(6)
+    x = (rng.random(shape) * 0.3 + (np.indices(shape)[-1] > shape[-1] // 2)).astype(np.float32)
+    for half in (False, True):
+        want = oracle.rof_tv(x, 0.05, 60, 0.005, half)
+        got = host(ROF_TV_cupy(dev(x), 0.05, 60, 0.005, 0, half))
+        assert rel(got, want) < (1e-4 if not half else 5e-4), (shape, half, rel(got, want))
+
+
 @pytest.mark.parametrize("shape", TV_SHAPES)
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [2, 1])
 def test_roftv_vs_oracle(oracle, ops, shape, variant):
     from tomobar_amd.regularisersCuPy import ROF_TV_cupy
     ops.set_variant("roftv", variant)
@@ -250,6 +280,12 @@ def test_tv_against_reference_fixtures(golden_dir, ops):
             assert rel(got, tv[f"{kind}_{cid}_{build}"]) < TOL, (key, build)
         n += 1
     assert n > 60
+
+
+@pytest.mark.default_arithmetic
+def test_shipped_tv_arithmetic_against_reference_fixtures(golden_dir, ops):
+    """The TV kernels as shipped (relaxed arithmetic) against the outputs of the reference's own kernel sources."""
+    test_tv_against_reference_fixtures(golden_dir, ops)
 
 
 def test_tv_errors_and_2d_squeeze():
@@ -358,7 +394,8 @@ def test_projector_pair_random_geometries(oracle, ops, seed):
 def test_tv_random_shapes(oracle, ops, seed):
     """seeded random 2D/3D shapes (straddling the 60/62-lane segments, the 4/8-row blocks and the z-chunk boundaries of
     the z-march kernels), random iteration counts (odd counts end with the single-iteration kernel), every option:
-    default PD_TV / ROF_TV kernels against the oracle, bit for bit"""
+    the exact-rounding builds of the shipped PD_TV / ROF_TV kernels against the oracle, bit for bit; the shipped
+    (relaxed-arithmetic) builds on the same inputs within 1e-5"""
     from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
     rng = np.random.default_rng(2000 + seed)
     if seed % 4 == 0:
@@ -369,11 +406,18 @@ def test_tv_random_shapes(oracle, ops, seed):
     iters = int(rng.integers(1, 9))
     half, mtv, nn = bool(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
     lam = float(rng.choice([0.01, 0.05, 0.3]))
+    ops.set_variant("pdtv", 2)
+    ops.set_variant("roftv", 2)
+    want_pd = oracle.pd_tv(x, lam, iters, mtv, nn, 8.0, half)
+    got = host(PD_TV_cupy(dev(x), lam, iters, mtv, nn, 8.0, 0, half))
+    assert np.array_equal(got, want_pd), ("pd", shape, iters, half, mtv, nn, np.abs(got - want_pd).max())
+    want_rof = oracle.rof_tv(x, lam, iters, 0.004, half)
+    got = host(ROF_TV_cupy(dev(x), lam, iters, 0.004, 0, half))
+    assert np.array_equal(got, want_rof), ("rof", shape, iters, half, np.abs(got - want_rof).max())
     ops.set_variant("pdtv", 0)
     ops.set_variant("roftv", 0)
-    want = oracle.pd_tv(x, lam, iters, mtv, nn, 8.0, half)
+    tol = 1e-5   # binary16 duals keep the exact arithmetic in the shipped build (bit-identical)
     got = host(PD_TV_cupy(dev(x), lam, iters, mtv, nn, 8.0, 0, half))
-    assert np.array_equal(got, want), ("pd", shape, iters, half, mtv, nn, np.abs(got - want).max())
-    want = oracle.rof_tv(x, lam, iters, 0.004, half)
+    assert rel(got, want_pd) < tol, ("pd shipped", shape, iters, half, mtv, nn, rel(got, want_pd))
     got = host(ROF_TV_cupy(dev(x), lam, iters, 0.004, 0, half))
-    assert np.array_equal(got, want), ("rof", shape, iters, half, np.abs(got - want).max())
+    assert rel(got, want_rof) < tol, ("rof shipped", shape, iters, half, rel(got, want_rof))

@@ -72,6 +72,13 @@ CASES = {
 }
 
 
+@pytest.mark.default_arithmetic
+@pytest.mark.parametrize("name", sorted(k for k, c in CASES.items() if c[4] is not None))
+def test_shipped_tv_arithmetic_against_reference_python_loops(outer, geom, name):
+    """The same reconstructions with the TV kernels as shipped (relaxed arithmetic), against the reference's own loops."""
+    test_against_reference_python_loops(outer, geom, name)
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_against_reference_python_loops(outer, geom, name):
     method, mk, dk, ak, reg = CASES[name]
@@ -190,6 +197,28 @@ def test_simple_iterative_methods_vs_oracle(oracle, geom):
         normr2 = normr2_new
     got = host(make(geom).CGLS(data_dict(geom), {"iterations": 4, "recon_mask_radius": None}))
     assert rel(got, x.reshape(nz, n, n)) < 1e-4  # inner products accumulate in a different order
+
+
+@pytest.mark.default_arithmetic
+def test_medium_size_fista_os_pdtv_shipped_arithmetic(oracle):
+    """The shipped (relaxed-arithmetic) PD_TV inside a FISTA-OS run of several outer iterations: <= 1e-5 from the oracle
+    (north-star tolerance), i.e. the per-call 1e-7 differences do not grow through the outer loop."""
+    from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    nz, det, na, os_n = 12, 160, 72, 6
+    angles = np.linspace(0, np.pi, na, endpoint=False)
+    sino = oracle.shepp_logan_sino(det, nz, det, angles) / det
+    sino += 0.01 * np.random.default_rng(0).standard_normal(sino.shape).astype(np.float32)
+    P = oracle.Projector(nz, det, det, angles, 0.0, os_n)
+    Lc = oracle.power_method(P, np.random.default_rng(1).standard_normal((nz, det, det)).astype(np.float32))
+    reg = {"method": "PD_TV", "regul_param": 0.002, "iterations": 30, "methodTV": 0, "PD_LipschitzConstant": 12.0}
+    want = oracle.fista(P, sino, 5, Lc, True, reg)
+    rt = RecToolsIRCuPy(det, 0, nz, 0.0, angles, det, 0, os_n)
+    rec = rt.FISTA({"projection_data": sino, "data_axes_labels_order": ["detY", "angles", "detX"]},
+                   {"iterations": 5, "lipschitz_const": Lc, "nonnegativity": True, "recon_mask_radius": None},
+                   {"method": "PD_TV", "regul_param": 0.002, "iterations": 30})
+    r = rel(host(rec), want)
+    print("FISTA-OS(6) x 5 + PD_TV(30), shipped arithmetic: rel-L2 vs oracle =", r)
+    assert r < TOL, r
 
 
 def test_medium_size_fista_os_pdtv_pad_vs_oracle(oracle):

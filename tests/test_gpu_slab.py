@@ -21,7 +21,7 @@ def _copy_halos(states, b):
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("half", [False, True])
-@pytest.mark.parametrize("variant", [0, 1, "ranges"])
+@pytest.mark.parametrize("variant", [0, 2, 1, "ranges"])
 def test_pdtv_slabs_equal_whole_volume(world, half, variant):
     ranges = variant == "ranges"  # the overlapped schedule of pd_tv_slab: edge planes first, then the interior
     variant = 0 if ranges else variant

@@ -38,6 +38,9 @@ def _worker(rank, world, port, case):
         from oracle import tomo_oracle as O
         from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
         from tomobar_amd.slab import SlabComm, slab_bounds
+        from tomobar_amd import ops
+        ops.set_variant("pdtv", 2)   # exact-rounding TV kernels: the comparison with the oracle below is bit for bit
+        ops.set_variant("roftv", 2)
         dev = torch.device("cuda", 0)
         nz, n, na, os_n = case["nz"], 40, 36, case["os"]
         angles = np.linspace(0, np.pi, na, endpoint=False)

@@ -149,7 +149,7 @@ static int pd_zmarch2_launch(PdArgs a, hipStream_t st)
     if (ND == 3) {
         const long waves_xy = (long)gx * gy * WX * WY;
         // measured: 48 waves per SIMD's worth of z-chunks (shorter marches, better balance) beats 8-16 by ~5 %
-        static const long want_per_simd = getenv("TOMO_PD_WANT") ? atol(getenv("TOMO_PD_WANT")) : 48;
+        const long want_per_simd = 48;
         const long want = 256L * 4 * want_per_simd;
         chunks = (int)((want + waves_xy - 1) / waves_xy);
         const int max_chunks = ceil_div(nout, 32);

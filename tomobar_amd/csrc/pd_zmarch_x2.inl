@@ -12,7 +12,7 @@
 // stage B rows -1..RY-1 and lanes 1..61, output rows 0..RY-1 and lanes 2..61 (60 of 64).  Same workgroup shape and
 // lockstep barrier as pd_zmarch2 so that the overlapping rows / lines of neighbouring waves merge in L1.
 // Arithmetic and rounding are those of two successive single iterations (bit-identical; tests/test_gpu_parity.py).
-template <typename T, bool NONNEG, bool ANISO, int RY, int WX, int WY>
+template <typename T, bool NONNEG, bool ANISO, bool FAST, int RY, int WX, int WY>
 __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_x2_kernel(PdArgs a, int gx, int gy, int gy_per_xcd)
 {
     int j = (int)blockIdx.x >> 3;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_x2_kernel(PdArgs a, in
                 g[1] = ((y == dy - 1) ? uy_mirror : Uc[r + 3]) - u;
                 g[2] = Un[r + 2] - u;
                 float p[3] = {Pa[0][r + 2], Pa[1][r + 2], Pa[2][r + 2]};
-                pd_dual<3, ANISO>(p, g, a.sigma);
+                pd_dual_t<ANISO, FAST>(p, g, a.sigma);
                 Pa[0][r + 2] = p[0]; Pa[1][r + 2] = p[1]; Pa[2][r + 2] = p[2];
             }
             // ---------------- stage A primal U^{n+1}(t), rows -1..RY
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_x2_kernel(PdArgs a, in
                 const float pz = (t > 0) ? carryA3[r + 1] : 0.0f;
                 float div = (-(Pa[0][r + 2] - px)) + (-(Pa[1][r + 2] - py));
                 div = div + (-(Pa[2][r + 2] - pz));
-                V2[r + 1] = pd_primal(Uc[r + 2], InA[r + 1], div, a.tau, a.lt, a.theta, NONNEG);
+                V2[r + 1] = pd_primal_t<FAST>(Uc[r + 2], InA[r + 1], div, a.tau, a.lt, a.inv1lt, a.theta, NONNEG);
             }
         } else {
 #pragma unroll
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_x2_kernel(PdArgs a, in
                 if (sizeof(T) == 2) {  // P^{n+1} as the next iteration would read it back from binary16 storage
                     p[0] = DualIO<T>::rt(p[0]); p[1] = DualIO<T>::rt(p[1]); p[2] = DualIO<T>::rt(p[2]);
                 }
-                pd_dual<3, ANISO>(p, g, a.sigma);
+                pd_dual_t<ANISO, FAST>(p, g, a.sigma);
                 Pb[0][r + 1] = p[0]; Pb[1][r + 1] = p[1]; Pb[2][r + 1] = p[2];
             }
             const bool emit_plane = (s >= zc0);
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_x2_kernel(PdArgs a, in
                 const float pz = (s > 0) ? carryB3[r] : 0.0f;
                 float div = (-(Pb[0][r + 1] - px)) + (-(Pb[1][r + 1] - py));
                 div = div + (-(Pb[2][r + 1] - pz));
-                const float uo = pd_primal(V1[r + 1], InPrev[r], div, a.tau, a.lt, a.theta, NONNEG);
+                const float uo = pd_primal_t<FAST>(V1[r + 1], InPrev[r], div, a.tau, a.lt, a.inv1lt, a.theta, NONNEG);
                 carryB3[r] = Pb[2][r + 1];
                 if (emit_plane && emit_lane && y < dy) {
                     *(float *)((char *)(a.u_out + sz * s) + off[r + 2]) = uo;
@@ -199,22 +199,23 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_x2_kernel(PdArgs a, in
     }
 }
 
-template <typename T, bool NONNEG, bool ANISO, int RY, int WX, int WY>
+template <typename T, bool NONNEG, bool ANISO, bool FAST, int RY, int WX, int WY>
 static int pd_zmarch_x2_launch(PdArgs a, hipStream_t st)
 {
     const int nout = a.out_end - a.out_begin;
     const int gx = ceil_div(ceil_div(a.dx, 60), WX), gy = ceil_div(a.dy, WY * RY);
     const int gy_per_xcd = ceil_div(gy, 8);
     const long waves_xy = (long)gx * gy * WX * WY;
-    static const long want_per_simd = getenv("TOMO_PD_WANT2") ? atol(getenv("TOMO_PD_WANT2")) : 32;
+    const long want_per_simd = 32;
     int chunks = (int)((256L * 4 * want_per_simd + waves_xy - 1) / waves_xy);
     const int max_chunks = ceil_div(nout, 48);  // two warm-up planes per chunk: keep chunks long
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
     a.zchunk = ceil_div(nout, chunks);
     chunks = ceil_div(nout, a.zchunk);
+    a.inv1lt = 1.0f / (1.0f + a.lt);
     const long blocks = 8L * gx * gy_per_xcd * chunks;
     if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one PD_TV launch");
-    pd_zmarch_x2_kernel<T, NONNEG, ANISO, RY, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd);
+    pd_zmarch_x2_kernel<T, NONNEG, ANISO, FAST, RY, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd);
     return TOMO_OK;
 }

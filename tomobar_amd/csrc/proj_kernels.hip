@@ -401,9 +401,8 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
         // would stage >= 1.25x what whole rows need (the 12-strided angles of an ordered subset), and it fits in LDS.
         bool done[4] = {false, false, false, false};
         {
-            static const int wide_env = getenv("TOMO_FP_WIDE") ? atoi(getenv("TOMO_FP_WIDE")) : -1;  // -1 auto
             size_t axis_off = s.table_offset;
-            for (int d = 0; d < 2 && wide_env != 0 && g_variant_fp == 0 && a.nu >= 768; ++d) {
+            for (int d = 0; d < 2 && g_variant_fp == 0 && a.nu >= 768; ++d) {
                 const int nc0 = s.n_class[2 * d], nc1 = s.n_class[2 * d + 1], nc = nc0 + nc1;
                 const size_t off_d = axis_off;
                 axis_off += nc;
@@ -416,7 +415,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 const double cost_tiles = (double)nut * (ceil_div(nc0, FP_A) * std::max(s.wbound[2 * d], 0) +
                                                          ceil_div(nc1, FP_A) * std::max(s.wbound[2 * d + 1], 0));
                 const double cost_rows = (double)nut_w * ceil_div(nc, FP_A) * wp;
-                const bool pays = wide_env == 1 || cost_tiles >= 1.25 * cost_rows;
+                const bool pays = cost_tiles >= 1.25 * cost_rows;
                 const int passes_w = ceil_div(wp, 1024);
                 // rows per chunk: 4 (or 2) double-buffered rows up to two column passes; detectors wider than 2048
                 // (3-5 passes, BASELINE configs[4] is 2560 wide) keep ONE tile (two barriers per chunk) of as many
@@ -497,8 +496,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 // single-buffered beyond); wider ones (detectors wider than 1024 whose whole-row form does not fit in
                 // LDS) and variant 2 run the synchronous form: stage, barrier, sample, barrier, with a small LDS
                 // footprint so that several workgroups per CU hide the staging latency.
-                static const int pipe_max = getenv("TOMO_FP_PIPE_MAX") ? atoi(getenv("TOMO_FP_PIPE_MAX")) : FP_MAX_WPITCH;
-                if (g_variant_fp == 2 || t.wpitch > std::min(pipe_max, FP_MAX_WPITCH)) {
+                if (g_variant_fp == 2 || t.wpitch > FP_MAX_WPITCH) {
                     const int kcs = std::max(1, std::min(8, 40000 / (t.wpitch * 16)));
                     const size_t sm = (size_t)kcs * t.wpitch * 16;
                     TOMO_REQUIRE(sm <= 64 * 1024, "forward-projection window does not fit in LDS");

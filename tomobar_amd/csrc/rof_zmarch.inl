@@ -9,7 +9,7 @@
 // z = 0 plane, whose backward difference reflects to D3 of plane 1 (:228-235): it is evaluated in the first step.
 struct RofD { float d1, d2, d3; };
 
-template <int ND, bool HALF>
+template <int ND, bool HALF, bool FAST>
 __device__ __forceinline__ RofD rof_eval(float u, float u_i1, float u_i2, float u_j1, float u_j2, float u_k1, float u_k2)
 {
     // reference naming: "x" differences run along j (rows), "y" along i (lanes)  (rudin_osher...cu:183-188)
@@ -17,15 +17,19 @@ __device__ __forceinline__ RofD rof_eval(float u, float u_i1, float u_i2, float 
     const float ny1 = u_i1 - u, ny0 = u - u_i2;
     const float dxm = rof_mm(nx0, nx1), dym = rof_mm(ny0, ny1);
     RofD d;
+    // FAST: float32 sum + v_rsq_f32 instead of the reference's double-precision sum, IEEE sqrt and IEEE divide
+    auto nrm = [](float nom, float d1, float d2, float d3) {
+        return FAST ? nom * __builtin_amdgcn_rsqf(((d1 + d2) + d3) + 1.0e-8f) : rof_norm(nom, d1, d2, d3);
+    };
     if (ND == 3) {
         const float nz1 = u_k1 - u, nz0 = u - u_k2;
         const float dzm = rof_mm(nz0, nz1);
-        d.d1 = rof_norm(nx1, nx1 * nx1, dym, dzm);
-        d.d2 = rof_norm(ny1, dxm, ny1 * ny1, dzm);
-        d.d3 = rof_norm(nz1, dxm, dym, nz1 * nz1);
+        d.d1 = nrm(nx1, nx1 * nx1, dym, dzm);
+        d.d2 = nrm(ny1, dxm, ny1 * ny1, dzm);
+        d.d3 = nrm(nz1, dxm, dym, nz1 * nz1);
     } else {
-        d.d1 = rof_norm(nx1, nx1 * nx1, dym, 0.0f);
-        d.d2 = rof_norm(ny1, dxm, ny1 * ny1, 0.0f);
+        d.d1 = nrm(nx1, nx1 * nx1, dym, 0.0f);
+        d.d2 = nrm(ny1, dxm, ny1 * ny1, 0.0f);
         d.d3 = 0.0f;
     }
     if (HALF) {
@@ -34,7 +38,7 @@ __device__ __forceinline__ RofD rof_eval(float u, float u_i1, float u_i2, float 
     return d;
 }
 
-template <int ND, bool HALF, int RY, int WX, int WY>
+template <int ND, bool HALF, bool FAST, int RY, int WX, int WY>
 __global__ __launch_bounds__(64 * WX * WY) void rof_zmarch_kernel(RofArgs a, int gx, int gy, int gy_per_xcd, int zchunk)
 {
     int j = (int)blockIdx.x >> 3;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(64 * WX * WY) void rof_zmarch_kernel(RofArgs a, int
             const float u_j2 = (y == 0) ? mid[r + 3] : mid[r + 1];
             const float u_k1 = k_last ? lo[r + 2] : hi[r + 2];
             const float u_k2 = k_first ? hi[r + 2] : lo[r + 2];
-            D[r + 1] = rof_eval<ND, HALF>(u, u_i1, u_i2, u_j1, u_j2, u_k1, u_k2);
+            D[r + 1] = rof_eval<ND, HALF, FAST>(u, u_i1, u_i2, u_j1, u_j2, u_k1, u_k2);
         }
     };
 
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(64 * WX * WY) void rof_zmarch_kernel(RofArgs a, int
     }
 }
 
-template <int ND, bool HALF, int RY, int WX, int WY>
+template <int ND, bool HALF, bool FAST, int RY, int WX, int WY>
 static int rof_zmarch_launch(const RofArgs &a, hipStream_t st)
 {
     const int nout = a.out_end - a.out_begin;
@@ -169,6 +173,6 @@ static int rof_zmarch_launch(const RofArgs &a, hipStream_t st)
     chunks = ceil_div(nout, zchunk);
     const long blocks = 8L * gx * gy_per_xcd * chunks;
     if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one ROF_TV launch");
-    rof_zmarch_kernel<ND, HALF, RY, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd, zchunk);
+    rof_zmarch_kernel<ND, HALF, FAST, RY, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd, zchunk);
     return TOMO_OK;
 }

@@ -4,14 +4,16 @@
 //   tomobar/cuda_kernels/primal_dual_for_total_variation.cu:125-261 (3D), :360-452 (2D)
 //   tomobar/cuda_kernels/rudin_osher_fatemi_total_variation.cu:66-137 (2D), :156-238 (3D)
 // How it is computed here is MI355X-first:
-//   * PD_TV default: pd_zmarch_x2.inl, TWO iterations per pass through HBM.  A lane owns 4 consecutive rows of one
-//     x column and marches along z; +-y neighbours are other registers of the same lane, +-x neighbours come from
-//     DPP wave shifts (2 halo lanes either side), the z-1 duals are carried in registers, iteration n+1 -> n+2 runs
-//     one plane behind iteration n -> n+1 in the same wave.  2 x 2 waves per workgroup walk z in lockstep so that
-//     the lines they share merge in L1.  Odd iteration counts / the single-step slab entry use pd_zmarch2.inl (one
-//     iteration, 8 rows per lane).  Measured history and PMC evidence: DESIGN.md sections 4 and 6.
+//   * PD_TV default: pd_tile.inl, TWO iterations per pass through HBM.  A lane owns 4 consecutive rows of one x column
+//     and marches along z; +-y neighbours are other registers of the same lane, +-x neighbours come from DPP wave
+//     shifts (2 halo lanes either side), the z-1 duals are carried in registers, iteration n+1 -> n+2 runs one plane
+//     behind iteration n -> n+1 in the same wave.  A workgroup is a stack of 8 waves owning 32 consecutive rows; the
+//     one row a wave needs from its neighbour goes through LDS, only the tile carries a two-row halo.  Odd iteration
+//     counts / the single-step slab entry use pd_zmarch2.inl (one iteration, 8 rows per lane).
+//     Measured history and PMC evidence: DESIGN.md sections 4 and 6.
 //   * variant 1 ("pervoxel"): one thread per voxel, neighbours' duals recomputed from global memory; variant 2: the
-//     first, unsynchronised z-march (63 outputs per wave).  Both kept as independent implementations for A/B checks.
+//     round-1 two-iteration kernel (pd_zmarch_x2.inl: every wave re-computes its own row halos).  Both are kept as
+//     independent implementations for A/B checks.  Variants 10-13: tile shapes / relaxed arithmetic (measurement).
 //   * ROF_TV: rof_zmarch.inl, divergence and update fused on the same z-march skeleton: the D fields never reach
 //     HBM (12 B/voxel/iteration) and are evaluated once per voxel.  Variant 1: per-voxel form.
 // All arithmetic is float32 with the rounding sequence of oracle/tomo_oracle.c (explicit fmaf, -ffp-contract=off).
@@ -97,6 +99,7 @@ struct PdArgs {
     int last_is_edge;   // plane planes-1 is the global last plane
     float sigma, tau, lt, theta;
     int zchunk;       // planes per z-chunk (zmarch)
+    float inv1lt;     // 1 / (1 + lt), relaxed-arithmetic kernels only
 };
 
 // ------------------------------------------------------------------------------------------ PD variant 1
@@ -146,131 +149,24 @@ __global__ __launch_bounds__(256) void pd_pervoxel_kernel(PdArgs a)
     for (int c = 0; c < ND; ++c) DualIO<T>::st((T *)a.p_out[c], idx, p[c]);
 }
 
-// ------------------------------------------------------------------------------------------ PD variant 0
-// Wave-autonomous register-blocked z-march.  Block = 4 waves stacked along y.
-//   lane l of x-segment s  <->  x = 63*s - 1 + l   (lane 0 = halo lane, lanes 1..63 produce output)
-//   row slot r in [-1, RY) <->  y = y0 + r         (slot -1 = halo row, slots 0..RY-1 produce output)
-template <typename T, int ND, bool NONNEG, bool ANISO, int RY>
-__global__ __launch_bounds__(256) void pd_zmarch_kernel(PdArgs a)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int x = (int)blockIdx.x * 63 - 1 + lane;
-    const int y0 = ((int)blockIdx.y * 4 + wave) * RY;
-    if (y0 >= a.dy) return;  // whole wave idle (no barriers in this kernel)
-    const int zc0 = a.out_begin + (int)blockIdx.z * a.zchunk;
-    const int zc1 = min(zc0 + a.zchunk, a.out_end);
-
-    const int dx = a.dx, dy = a.dy;
-    const size_t sy = (size_t)dx, sz = (size_t)dx * dy;
-    const bool x_ok = (x >= 0) && (x < dx);
-    const bool x_last = (x == dx - 1);
-    const bool x_has_prev = (x > 0);
-    const bool emit_lane = x_ok && (lane >= 1);
-    const T *P_in[3] = {(const T *)a.p_in[0], (const T *)a.p_in[1], (const T *)a.p_in[2]};
-    T *P_out[3] = {(T *)a.p_out[0], (T *)a.p_out[1], (T *)a.p_out[2]};
-
-    // row validity: slot r valid when 0 <= y0 + r < dy
-    auto row_ok = [&](int r) { int y = y0 + r; return y >= 0 && y < dy; };
-    auto ldU = [&](int plane, int r) -> float {
-        return (x_ok && row_ok(r)) ? a.u_in[(size_t)x + sy * (y0 + r) + sz * plane] : 0.0f;
-    };
-
-    float Uc[RY + 2];       // current plane, slots -1..RY  (index r+1)
-    float Un[RY + 2];       // next plane
-    float carry3[RY];       // updated P3 of the previous plane, slots 0..RY-1
-#pragma unroll
-    for (int r = 0; r < RY; ++r) carry3[r] = 0.0f;
-
-    const int zstart = (ND == 3 && zc0 > 0) ? zc0 - 1 : zc0;  // one warm-up plane to build carry3
-#pragma unroll
-    for (int r = -1; r <= RY; ++r) Uc[r + 1] = ldU(zstart, r);
-
-    for (int z = zstart; z < zc1; ++z) {
-        const bool emit_plane = (z >= zc0);
-        const bool z_last = (ND == 3) && (z == a.planes - 1) && a.last_is_edge;
-        // ---- next plane (or the mirrored previous plane at the global far edge)
-        if (ND == 3) {
-            if (!z_last) {
-#pragma unroll
-                for (int r = -1; r <= RY; ++r) Un[r + 1] = (z + 1 < a.planes) ? ldU(z + 1, r) : 0.0f;
-            } else {
-#pragma unroll
-                for (int r = -1; r <= RY; ++r) Un[r + 1] = (z > 0) ? ldU(z - 1, r) : 0.0f;
-            }
-        }
-        // ---- duals of slots -1..RY-1
-        float Pn[3][RY + 1];
-#pragma unroll
-        for (int r = -1; r < RY; ++r) {
-            const int y = y0 + r;
-            const bool ok = x_ok && row_ok(r);
-            const size_t idx = (size_t)(x_ok ? x : 0) + sy * (ok ? y : 0) + sz * z;
-            float u = Uc[r + 1];
-            // +x neighbour: lane+1, except lane 63 which fetches it (served by L2)
-            float ux = __shfl_down(u, 1, 64);
-            if (lane == 63) ux = (ok && x + 1 < dx) ? a.u_in[idx + 1] : 0.0f;
-            float uxm = __shfl_up(u, 1, 64);  // x-1 (for the far-edge mirror)
-            if (lane == 0) uxm = (ok && x > 0) ? a.u_in[idx - 1] : 0.0f;
-            float g[3] = {0.0f, 0.0f, 0.0f};
-            g[0] = (x_last ? (x_has_prev ? uxm : 0.0f) : ux) - u;
-            {
-                float uy;
-                if (y == dy - 1) uy = (y > 0) ? Uc[r >= 0 ? r : 0] : 0.0f;  // slot -1 is never the last row
-                else uy = Uc[r + 2];
-                g[1] = uy - u;
-            }
-            if (ND == 3) g[2] = Un[r + 1] - u;
-            float p[3] = {0.0f, 0.0f, 0.0f};
-            if (ok) {
-#pragma unroll
-                for (int c = 0; c < ND; ++c) p[c] = DualIO<T>::ld(P_in[c], idx);
-            }
-            pd_dual<ND, ANISO>(p, g, a.sigma);
-#pragma unroll
-            for (int c = 0; c < ND; ++c) Pn[c][r + 1] = p[c];
-        }
-        // ---- primal step for slots 0..RY-1
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            const int y = y0 + r;
-            float p1l = __shfl_up(Pn[0][r + 1], 1, 64);  // updated P1 at x-1 (shuffle executed by all lanes)
-            if (emit_plane && emit_lane && y < dy) {
-                const size_t idx = (size_t)x + sy * y + sz * z;
-                float px = x_has_prev ? p1l : 0.0f;
-                float py = (y > 0) ? Pn[1][r] : 0.0f;
-                float div = (-(Pn[0][r + 1] - px)) + (-(Pn[1][r + 1] - py));
-                if (ND == 3) {
-                    float pz = (z > 0) ? carry3[r] : 0.0f;
-                    div = div + (-(Pn[2][r + 1] - pz));
-                }
-                a.u_out[idx] = pd_primal(Uc[r + 1], a.in[idx], div, a.tau, a.lt, a.theta, NONNEG);
-#pragma unroll
-                for (int c = 0; c < ND; ++c) DualIO<T>::st(P_out[c], idx, Pn[c][r + 1]);
-            }
-            if (ND == 3) carry3[r] = Pn[2][r + 1];
-        }
-        if (ND == 3) {
-#pragma unroll
-            for (int r = 0; r < RY + 2; ++r) Uc[r] = Un[r];
-        }
-    }
-}
-
 #include "pd_zmarch2.inl"
+#include "pd_tile.inl"
 #include "pd_zmarch_x2.inl"
 
-// two iterations in one pass (3D, whole volume only).  variant 0: 4 rows; 6: 6 rows; 7: 4x1 waves 4 rows
+// two iterations in one pass (3D).  variant 0 (default): pd_zmarch_x2 (every wave re-computes its own row halos) with
+// relaxed arithmetic for float32 duals and exact arithmetic for binary16 duals (one flipped binary16 rounding is 5e-4 of
+// a dual value: relaxed arithmetic cannot hold the 1e-5 parity bar there); 2: the reference's exact rounding sequence
+// for both (bit-identical to the oracle); 3: relaxed arithmetic for both;
+// 10 / 11: the workgroup-tile kernel (LDS row halos), exact / relaxed -- measured slower, see pd_tile.inl
 template <typename T>
 int pd_pair_launch(const PdArgs &a, int methodTV, int nonneg, int variant, hipStream_t st)
 {
-#define PD_X2(NN, AN)                                                                                          \
-    /* measured, 1024^3 f32 duals, ms per iteration: 2x2 waves 5.60 | 2x1 5.74 | 4x1 6.20 | 4x2 7.10 | 8x1 8.28 */ \
-    (variant == 6 ? pd_zmarch_x2_launch<T, NN, AN, 4, 1, 2>(a, st)                                              \
-                  : variant == 7 ? pd_zmarch_x2_launch<T, NN, AN, 4, 2, 1>(a, st)                               \
-                  : variant == 8 ? pd_zmarch_x2_launch<T, NN, AN, 4, 1, 4>(a, st)                               \
-                  : variant == 9 ? pd_zmarch_x2_launch<T, NN, AN, 4, 2, 4>(a, st)                               \
-                                 : pd_zmarch_x2_launch<T, NN, AN, 4, 2, 2>(a, st))
+#define PD_X2(NN, AN)                                                                         \
+    (variant == 10   ? pd_tile_launch<T, NN, AN, false, 4, 1, 8>(a, st)                       \
+     : variant == 11 ? pd_tile_launch<T, NN, AN, true, 4, 1, 8>(a, st)                        \
+     : variant == 3  ? pd_zmarch_x2_launch<T, NN, AN, true, 4, 2, 2>(a, st)                   \
+     : variant == 2  ? pd_zmarch_x2_launch<T, NN, AN, false, 4, 2, 2>(a, st)                  \
+                     : pd_zmarch_x2_launch<T, NN, AN, sizeof(T) == 4, 4, 2, 2>(a, st))
     int rc;
     if (!nonneg && !methodTV) rc = PD_X2(false, false);
     else if (nonneg && !methodTV) rc = PD_X2(true, false);
@@ -291,32 +187,11 @@ int pd_launch(const PdArgs &a0, int variant, hipStream_t st)
     if (variant == 1) {
         dim3 grid(ceil_div(a.dx, 256), a.dy, nout);
         pd_pervoxel_kernel<T, ND, NONNEG, ANISO><<<grid, 256, 0, st>>>(a);
-    } else if (variant == 0 || (variant >= 3 && variant <= 5)) {
+    } else {
         // measured on MI355X, 1024^3 f32 duals (profiles/r1_pdtv_pmc.txt): 4x2 waves x 8 rows, lockstep = 8.6 ms;
         // 4x4 waves x 4 rows = 9.2 ms; 4x1 x 8 rows = 8.7 ms; unsynchronised waves (1x4, 4 rows) = 12.3-14 ms
-        int rc = (variant == 0)   ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 8, true, 4, 2>(a, st)
-                 : (variant == 3) ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 4, true, 4, 4>(a, st)
-                 : (variant == 4) ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 8, true, 4, 1>(a, st)
-                                  : pd_zmarch2_launch<T, ND, NONNEG, ANISO, 4, false, 1, 4>(a, st);
+        int rc = pd_zmarch2_launch<T, ND, NONNEG, ANISO, 8, true, 4, 2>(a, st);
         if (rc != TOMO_OK) return rc;
-    } else {
-        constexpr int RY = 4;
-        // enough z-chunks to fill the chip (>= ~8 waves per SIMD) but long enough to amortise the warm-up plane
-        const int gx = ceil_div(a.dx, 63), gy = ceil_div(a.dy, 4 * RY);
-        int chunks = 1;
-        if (ND == 3) {
-            const long waves_xy = (long)gx * gy * 4;
-            const long want = 256L * 4 * 8;
-            chunks = (int)((want + waves_xy - 1) / waves_xy);
-            if (chunks < 1) chunks = 1;
-            int max_chunks = ceil_div(nout, 16);
-            if (chunks > max_chunks) chunks = max_chunks;
-            if (chunks < 1) chunks = 1;
-        }
-        a.zchunk = ceil_div(nout, chunks);
-        chunks = ceil_div(nout, a.zchunk);
-        dim3 grid(gx, gy, chunks);
-        pd_zmarch_kernel<T, ND, NONNEG, ANISO, RY><<<grid, 256, 0, st>>>(a);
     }
     TOMO_LAUNCH_CHECK();
     return TOMO_OK;
@@ -333,7 +208,7 @@ int pd_dispatch(const PdArgs &a, int methodTV, int nonneg, int variant, hipStrea
 
 int pd_iter(const PdArgs &a, int nd, int methodTV, int nonneg, int half, hipStream_t st)
 {
-    const int v = (g_variant_pdtv >= 6 && g_variant_pdtv <= 9) ? 0 : g_variant_pdtv;  // 6-9 only differ in the paired kernel
+    const int v = g_variant_pdtv == 1 ? 1 : 0;  // the other variants only differ in the paired kernel
     if (nd == 3) return half ? pd_dispatch<__half, 3>(a, methodTV, nonneg, v, st) : pd_dispatch<float, 3>(a, methodTV, nonneg, v, st);
     return half ? pd_dispatch<__half, 2>(a, methodTV, nonneg, v, st) : pd_dispatch<float, 2>(a, methodTV, nonneg, v, st);
 }
@@ -417,13 +292,14 @@ __global__ __launch_bounds__(256) void rof_pervoxel_kernel(RofArgs a)
 
 #include "rof_zmarch.inl"
 
+// variant 0: z-march with relaxed arithmetic (default); 2: z-march, the reference's exact rounding sequence;
+// 1: per-voxel kernel (independent implementation)
 template <int ND, bool HALF>
 int rof_zmarch_dispatch(const RofArgs &a, int variant, hipStream_t st)
 {
-    int rc = (variant == 2)   ? rof_zmarch_launch<ND, HALF, 4, 4, 2>(a, st)
-             : (variant == 3) ? rof_zmarch_launch<ND, HALF, 8, 4, 1>(a, st)
-             : (variant == 4) ? rof_zmarch_launch<ND, HALF, 4, 2, 2>(a, st)
-                              : rof_zmarch_launch<ND, HALF, 8, 2, 2>(a, st);
+    // binary16 D fields keep the exact arithmetic by default (see pd_pair_launch); variant 3 relaxes them too
+    int rc = (variant == 2 || (HALF && variant != 3)) ? rof_zmarch_launch<ND, HALF, false, 8, 2, 2>(a, st)
+                                                      : rof_zmarch_launch<ND, HALF, true, 8, 2, 2>(a, st);
     if (rc != TOMO_OK) return rc;
     TOMO_LAUNCH_CHECK();
     return TOMO_OK;
@@ -460,14 +336,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // started `tv_skew()` bytes further than the plain packing would (k-th array: k * skew).
 static size_t tv_skew()
 {
-    static long skew = -1;
-    if (skew < 0) {
-        const char *e = getenv("TOMO_TV_SKEW");
-        skew = e ? atol(e) : 69888;  // 68 KiB + 256 B: measured -13 % on the 1024^3 PD_TV iteration vs 0
-        if (skew < 0) skew = 0;
-        skew = (skew + 255) / 256 * 256;
-    }
-    return (size_t)skew;
+    return 69888;  // 68 KiB + 256 B: measured -13 % on the 1024^3 PD_TV iteration vs 0
 }
 
 extern "C" size_t tomo_pdtv_scratch_bytes(int dx, int dy, int dz, int nd, int half)
@@ -520,7 +389,7 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
     // 3D volumes run two iterations per launch (pd_zmarch_x2) while at least two remain; variants 1-5 keep one
     // iteration per launch (A/B measurement)
     const int v = g_variant_pdtv;
-    const bool pairs = (nd == 3) && (v == 0 || (v >= 6 && v <= 9)) && !getenv("TOMO_PD_NOPAIR");
+    const bool pairs = (nd == 3) && v != 1;
     int launches = 0;
     for (int it = 0; it < iters;) launches += 1, it += (pairs && iters - it >= 2) ? 2 : 1;
     tomo_prof_scope prof(PROF_PDTV, st, launches);
@@ -603,7 +472,8 @@ extern "C" int tomo_pdtv_pair_slab_range(int device, const float *in_dev, const 
     a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = z_end - z_begin;
     hipStream_t st = as_stream(stream);
     tomo_prof_scope prof(PROF_PDTV, st, 1);
-    return half ? pd_pair_launch<__half>(a, methodTV, nonneg, 0, st) : pd_pair_launch<float>(a, methodTV, nonneg, 0, st);
+    const int v = (g_variant_pdtv == 0 || g_variant_pdtv == 3) ? g_variant_pdtv : 2;  // slabs always run the per-wave-halo kernel
+    return half ? pd_pair_launch<__half>(a, methodTV, nonneg, v, st) : pd_pair_launch<float>(a, methodTV, nonneg, v, st);
 }
 
 extern "C" int tomo_roftv(int device, const float *in_dev, float *out_dev, int dx, int dy, int dz, int nd,

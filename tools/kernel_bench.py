@@ -48,14 +48,14 @@ for variant in (0, 2, 1):
     print(f"FP  variant {variant}: {ms:8.3f} ms  {4*(S+V)/ms/1e6:8.1f} GB/s alg  {V*NA/ms/1e6:8.1f} GUPS")
 ops.set_variant("fp", 0)
 IT = 10
-for variant in (0, 1):
+for variant in (0, 2, 10, 11, 1):
     ops.set_variant("pdtv", variant)
     for half in (False, True):
         ms = timeit(lambda: PD_TV_cupy(vol, 0.01, IT, 0, 1, 12.0, 0, half, out=out_v)) / IT
         bpv = 24 if half else 36
         print(f"PD_TV v{variant} half={int(half)}: {ms:8.3f} ms/iter  {bpv*V/ms/1e6:8.1f} GB/s alg")
 ops.set_variant("pdtv", 0)
-for variant in (0, 2, 3, 4, 1):
+for variant in (0, 2, 1):
     ops.set_variant("roftv", variant)
     ms = timeit(lambda: ROF_TV_cupy(vol, 0.01, IT, 0.001, 0, False, out=out_v)) / IT
     print(f"ROF_TV v{variant}     : {ms:8.3f} ms/iter  {12*V/ms/1e6:8.1f} GB/s alg")

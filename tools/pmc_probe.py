@@ -16,7 +16,7 @@ NA = int(sys.argv[4]) if len(sys.argv) > 4 else 75
 vol = torch.rand((NZ, N, N), device="cuda")
 out = torch.empty_like(vol)
 if what.startswith("pdtv"):
-    ops.set_variant("pdtv", int(what[4]))
+    ops.set_variant("pdtv", int(what[4:].rstrip("h")))
     PD_TV_cupy(vol, 0.01, 4, 0, 1, 12.0, 0, what.endswith("h"), out=out)
 elif what == "roftv":
     ROF_TV_cupy(vol, 0.01, 4, 0.001, 0, False, out=out)
