@@ -186,7 +186,7 @@ def test_fused_residual_and_gradient_steps(oracle, ops):
 
 # ------------------------------------------------------------------------------------------ TV operators
 TV_SHAPES = [(6, 9, 13), (1, 20, 17), (12, 1, 70), (10, 11, 1), (8, 8, 8), (3, 5, 131), (24, 19), (20, 70, 150)]
-PD_EXACT_VARIANTS = [2, 1, 10]   # bit-identical to the oracle; 0 (default), 11: relaxed arithmetic (tolerance)
+PD_EXACT_VARIANTS = [2, 1, 10, 20, 21]   # bit-identical to the oracle; 0 (default), 11: relaxed arithmetic (tolerance)
 
 
 @pytest.mark.parametrize("shape", TV_SHAPES)

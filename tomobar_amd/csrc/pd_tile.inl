@@ -17,27 +17,26 @@
 // duals are valid on tile rows [0, L-2], U^{n+1} on [1, L-2], stage B duals on [1, L-3], outputs on [2, L-3].
 // FAST = false: arithmetic and rounding of two successive single iterations (bit-identical to the oracle).
 // FAST = true : 1/(1+lt) hoisted to the host, v_rsq_f32 / v_rcp_f32 instead of IEEE sqrt + divide (<= 1e-6 relative).
-template <bool ANISO, bool FAST>
+template <bool ANISO, bool FAST, int ND = 3>
 __device__ __forceinline__ void pd_dual_t(float (&p)[3], const float (&g)[3], float sigma)
 {
     if (!FAST) {
-        pd_dual<3, ANISO>(p, g, sigma);
+        pd_dual<ND, ANISO>(p, g, sigma);
         return;
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) p[c] = fmaf(sigma, g[c], p[c]);
+    for (int c = 0; c < ND; ++c) p[c] = fmaf(sigma, g[c], p[c]);
     if (!ANISO) {
         float nrm = p[0] * p[0];
-        nrm = fmaf(p[1], p[1], nrm);
-        nrm = fmaf(p[2], p[2], nrm);
+#pragma unroll
+        for (int c = 1; c < ND; ++c) nrm = fmaf(p[c], p[c], nrm);
         const float r = nrm > 1.0f ? __builtin_amdgcn_rsqf(nrm) : 1.0f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) p[c] *= r;
+        for (int c = 0; c < ND; ++c) p[c] *= r;
     } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < ND; ++c)
             p[c] = fabsf(p[c]) > 1.0f ? copysignf(1.0f, p[c]) : p[c];  // p / |p| is exactly +-1 in IEEE arithmetic too
-        }
     }
 }
 

@@ -11,7 +11,7 @@
 // WX x WY waves per workgroup: WX consecutive x segments times WY consecutive row groups.  With LOCKSTEP the waves
 // of a workgroup walk z together (one barrier per plane) so that cache lines straddling two x segments and the halo
 // rows are requested by both users at the same moment and merge in the CU's L1 instead of becoming two HBM requests.
-template <typename T, int ND, bool NONNEG, bool ANISO, int RY, bool LOCKSTEP, int WX, int WY>
+template <typename T, int ND, bool NONNEG, bool ANISO, bool FAST, int RY, bool LOCKSTEP, int WX, int WY>
 __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch2_kernel(PdArgs a, int gx, int gy, int gy_per_xcd)
 {
     // ---- XCD-aware workgroup numbering (gx, gy count workgroups)
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch2_kernel(PdArgs a, int 
             g[1] = ((y == dy - 1) ? uy_mirror : Uc[r + 2]) - u;
             if (ND == 3) g[2] = Un[r + 1] - u;
             float p[3] = {Pl[0][r + 1], Pl[1][r + 1], ND == 3 ? Pl[2][r + 1] : 0.0f};
-            pd_dual<ND, ANISO>(p, g, a.sigma);
+            pd_dual_t<ANISO, FAST, ND>(p, g, a.sigma);
 #pragma unroll
             for (int c = 0; c < ND; ++c) Pn[c][r + 1] = p[c];
         }
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch2_kernel(PdArgs a, int 
                 div = div + (-(Pn[2][r + 1] - pz));
                 carry3[r] = Pn[2][r + 1];
             }
-            const float uo = pd_primal(Uc[r + 1], In[r], div, a.tau, a.lt, a.theta, NONNEG);
+            const float uo = pd_primal_t<FAST>(Uc[r + 1], In[r], div, a.tau, a.lt, a.inv1lt, a.theta, NONNEG);
             if (emit_plane && emit_lane && y < dy) {
                 *(float *)((char *)(a.u_out + sz * z) + off[r + 1]) = uo;
 #pragma unroll
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch2_kernel(PdArgs a, int 
     }
 }
 
-template <typename T, int ND, bool NONNEG, bool ANISO, int RY, bool LOCKSTEP, int WX = 1, int WY = 4>
+template <typename T, int ND, bool NONNEG, bool ANISO, bool FAST, int RY, bool LOCKSTEP, int WX = 1, int WY = 4>
 static int pd_zmarch2_launch(PdArgs a, hipStream_t st)
 {
     const int nout = a.out_end - a.out_begin;
@@ -158,8 +158,9 @@ static int pd_zmarch2_launch(PdArgs a, hipStream_t st)
     }
     a.zchunk = ceil_div(nout, chunks);
     chunks = ceil_div(nout, a.zchunk);
+    a.inv1lt = 1.0f / (1.0f + a.lt);
     const long blocks = 8L * gx * gy_per_xcd * chunks;
     if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one PD_TV launch");
-    pd_zmarch2_kernel<T, ND, NONNEG, ANISO, RY, LOCKSTEP, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd);
+    pd_zmarch2_kernel<T, ND, NONNEG, ANISO, FAST, RY, LOCKSTEP, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd);
     return TOMO_OK;
 }

@@ -149,30 +149,47 @@ __global__ __launch_bounds__(256) void pd_pervoxel_kernel(PdArgs a)
     for (int c = 0; c < ND; ++c) DualIO<T>::st((T *)a.p_out[c], idx, p[c]);
 }
 
-#include "pd_zmarch2.inl"
 #include "pd_tile.inl"
+#include "pd_zmarch2.inl"
 #include "pd_zmarch_x2.inl"
+#include "pd_zmarch_xk.inl"
 
-// two iterations in one pass (3D).  variant 0 (default): pd_zmarch_x2 (every wave re-computes its own row halos) with
-// relaxed arithmetic for float32 duals and exact arithmetic for binary16 duals (one flipped binary16 rounding is 5e-4 of
-// a dual value: relaxed arithmetic cannot hold the 1e-5 parity bar there); 2: the reference's exact rounding sequence
-// for both (bit-identical to the oracle); 3: relaxed arithmetic for both;
-// 10 / 11: the workgroup-tile kernel (LDS row halos), exact / relaxed -- measured slower, see pd_tile.inl
-template <typename T>
-int pd_pair_launch(const PdArgs &a, int methodTV, int nonneg, int variant, hipStream_t st)
+// Several iterations in one pass through HBM (3D).  `k` = iterations of this launch (2 or 3).
+//   variant 0 (shipped): float32 duals: relaxed arithmetic, k = 3 -> pd_zmarch_xk<K=3, 3 rows, 2x2 waves>,
+//                        k = 2 -> pd_zmarch_x2<2x4 waves>;  binary16 duals: exact arithmetic, k = 2 only (one flipped
+//                        binary16 rounding is 5e-4 of a dual value: relaxed arithmetic cannot hold the 1e-5 parity bar,
+//                        and the exact K = 3 kernel is VALU-bound: 6.4 vs 4.4 ms per iteration)
+//   variant 2: the reference's exact rounding sequence for both, k = 2 (pd_zmarch_x2, 2x2 waves; bit-identical to the oracle)
+//   variant 3: relaxed arithmetic for both, k = 2
+//   variant 20 / 21: pd_zmarch_xk with exact arithmetic, K = 2 / K = 3 (bit-identical to the oracle)
+//   variant 10 / 11: workgroup-tile kernel (LDS row halos), exact / relaxed -- measured slower, see pd_tile.inl
+static int pd_iters_per_launch(int variant, int half)
 {
-#define PD_X2(NN, AN)                                                                         \
-    (variant == 10   ? pd_tile_launch<T, NN, AN, false, 4, 1, 8>(a, st)                       \
-     : variant == 11 ? pd_tile_launch<T, NN, AN, true, 4, 1, 8>(a, st)                        \
-     : variant == 3  ? pd_zmarch_x2_launch<T, NN, AN, true, 4, 2, 2>(a, st)                   \
-     : variant == 2  ? pd_zmarch_x2_launch<T, NN, AN, false, 4, 2, 2>(a, st)                  \
-                     : pd_zmarch_x2_launch<T, NN, AN, sizeof(T) == 4, 4, 2, 2>(a, st))
+    if (variant == 21) return 3;
+    if (variant == 0 && !half) return 3;
+    return 2;
+}
+
+template <typename T>
+int pd_multi_launch(const PdArgs &a, int k, int methodTV, int nonneg, int variant, hipStream_t st)
+{
+    constexpr bool F32 = sizeof(T) == 4;
+#define PD_XK(NN, AN)                                                                                   \
+    (k == 3 ? (variant == 21 ? pd_zmarch_xk_launch<T, NN, AN, false, 3, 4, 2, 2>(a, st)                  \
+                             : pd_zmarch_xk_launch<T, NN, AN, F32, 3, 3, 2, 2>(a, st))                   \
+     : variant == 10 ? pd_tile_launch<T, NN, AN, false, 4, 1, 8>(a, st)                                  \
+     : variant == 11 ? pd_tile_launch<T, NN, AN, true, 4, 1, 8>(a, st)                                   \
+     : variant == 20 ? pd_zmarch_xk_launch<T, NN, AN, false, 2, 4, 2, 2>(a, st)                          \
+     : variant == 3  ? pd_zmarch_x2_launch<T, NN, AN, true, 4, 2, 4>(a, st)                              \
+     : (variant == 2 || variant == 21) ? pd_zmarch_x2_launch<T, NN, AN, false, 4, 2, 2>(a, st)           \
+     : F32 ? pd_zmarch_x2_launch<T, NN, AN, true, 4, 2, 4>(a, st)                                        \
+           : pd_zmarch_x2_launch<T, NN, AN, false, 4, 2, 2>(a, st))
     int rc;
-    if (!nonneg && !methodTV) rc = PD_X2(false, false);
-    else if (nonneg && !methodTV) rc = PD_X2(true, false);
-    else if (!nonneg && methodTV) rc = PD_X2(false, true);
-    else rc = PD_X2(true, true);
-#undef PD_X2
+    if (!nonneg && !methodTV) rc = PD_XK(false, false);
+    else if (nonneg && !methodTV) rc = PD_XK(true, false);
+    else if (!nonneg && methodTV) rc = PD_XK(false, true);
+    else rc = PD_XK(true, true);
+#undef PD_XK
     if (rc != TOMO_OK) return rc;
     TOMO_LAUNCH_CHECK();
     return TOMO_OK;
@@ -190,7 +207,11 @@ int pd_launch(const PdArgs &a0, int variant, hipStream_t st)
     } else {
         // measured on MI355X, 1024^3 f32 duals (profiles/r1_pdtv_pmc.txt): 4x2 waves x 8 rows, lockstep = 8.6 ms;
         // 4x4 waves x 4 rows = 9.2 ms; 4x1 x 8 rows = 8.7 ms; unsynchronised waves (1x4, 4 rows) = 12.3-14 ms
-        int rc = pd_zmarch2_launch<T, ND, NONNEG, ANISO, 8, true, 4, 2>(a, st);
+        // the shipped build (variant 0) runs float32 duals with relaxed arithmetic, like the multi-iteration kernels:
+        // the arithmetic of an iteration must not depend on how a run is cut into launches (slabs cut it differently)
+        const bool relaxed = (variant == 3) || (variant == 0 && sizeof(T) == 4);
+        int rc = relaxed ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, true, 8, true, 4, 2>(a, st)
+                         : pd_zmarch2_launch<T, ND, NONNEG, ANISO, false, 8, true, 4, 2>(a, st);
         if (rc != TOMO_OK) return rc;
     }
     TOMO_LAUNCH_CHECK();
@@ -208,7 +229,8 @@ int pd_dispatch(const PdArgs &a, int methodTV, int nonneg, int variant, hipStrea
 
 int pd_iter(const PdArgs &a, int nd, int methodTV, int nonneg, int half, hipStream_t st)
 {
-    const int v = g_variant_pdtv == 1 ? 1 : 0;  // the other variants only differ in the paired kernel
+    // 1: per-voxel kernel; 0 / 3: z-march with the shipped / relaxed arithmetic; everything else: exact z-march
+    const int v = (g_variant_pdtv == 1 || g_variant_pdtv == 0 || g_variant_pdtv == 3 || g_variant_pdtv == 11) ? (g_variant_pdtv == 11 ? 3 : g_variant_pdtv) : 2;
     if (nd == 3) return half ? pd_dispatch<__half, 3>(a, methodTV, nonneg, v, st) : pd_dispatch<float, 3>(a, methodTV, nonneg, v, st);
     return half ? pd_dispatch<__half, 2>(a, methodTV, nonneg, v, st) : pd_dispatch<float, 2>(a, methodTV, nonneg, v, st);
 }
@@ -297,7 +319,7 @@ __global__ __launch_bounds__(256) void rof_pervoxel_kernel(RofArgs a)
 template <int ND, bool HALF>
 int rof_zmarch_dispatch(const RofArgs &a, int variant, hipStream_t st)
 {
-    // binary16 D fields keep the exact arithmetic by default (see pd_pair_launch); variant 3 relaxes them too
+    // binary16 D fields keep the exact arithmetic by default (see pd_multi_launch); variant 3 relaxes them too
     int rc = (variant == 2 || (HALF && variant != 3)) ? rof_zmarch_launch<ND, HALF, false, 8, 2, 2>(a, st)
                                                       : rof_zmarch_launch<ND, HALF, true, 8, 2, 2>(a, st);
     if (rc != TOMO_OK) return rc;
@@ -386,17 +408,23 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
     // U_arrays[0] = data.copy() is not materialised: iteration 0 reads the caller's buffer directly;
     // duals start at zero (regularisersCuPy.py:221-223); every U / P output buffer is fully overwritten
     for (int c = 0; c < nd; ++c) TOMO_HIP(hipMemsetAsync(P[0][c], 0, pb, st));
-    // 3D volumes run two iterations per launch (pd_zmarch_x2) while at least two remain; variants 1-5 keep one
-    // iteration per launch (A/B measurement)
+    // 3D volumes run several iterations per launch (K = 3 or 2, see pd_multi_launch) while that many remain, then
+    // single iterations; variant 1 keeps one iteration per launch (independent implementation)
     const int v = g_variant_pdtv;
-    const bool pairs = (nd == 3) && v != 1;
+    const int kmax = (nd == 3 && v != 1) ? pd_iters_per_launch(v, half) : 1;
+    // cut `remaining` into launches of kmax / 2 / 1 iterations with as few single-iteration launches as possible
+    // (4 = 2 + 2, 7 = 3 + 2 + 2: a single iteration costs 1.7x an iteration of a fused launch)
+    auto step_of = [&](int remaining) {
+        if (kmax >= 3 && remaining >= 3 && remaining != 4) return 3;
+        return (remaining >= 2 && kmax >= 2) ? 2 : 1;
+    };
     int launches = 0;
-    for (int it = 0; it < iters;) launches += 1, it += (pairs && iters - it >= 2) ? 2 : 1;
+    for (int it = 0; it < iters;) launches += 1, it += step_of(iters - it);
     tomo_prof_scope prof(PROF_PDTV, st, launches);
     int cset = 0;  // buffer set holding the current iterate (iteration 0 reads the caller's buffer instead of U[0])
     for (int it = 0; it < iters;) {
-        const bool pair = pairs && (iters - it >= 2);
-        const int step = pair ? 2 : 1;
+        const int step = step_of(iters - it);
+        const bool pair = step >= 2;
         const int ib = cset, ob = cset ^ 1;
         PdArgs a;
         a.in = in_dev;
@@ -408,7 +436,7 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
         a.dx = dx; a.dy = dy; a.planes = dz; a.out_begin = 0; a.out_end = dz;
         a.first_is_edge = 1; a.last_is_edge = 1;
         a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = dz;
-        if (pair) rc = half ? pd_pair_launch<__half>(a, methodTV, nonneg, v, st) : pd_pair_launch<float>(a, methodTV, nonneg, v, st);
+        if (pair) rc = half ? pd_multi_launch<__half>(a, step, methodTV, nonneg, v, st) : pd_multi_launch<float>(a, step, methodTV, nonneg, v, st);
         else rc = pd_iter(a, nd, methodTV, nonneg, half, st);
         if (rc != TOMO_OK) return rc;
         cset = ob;
@@ -473,7 +501,7 @@ extern "C" int tomo_pdtv_pair_slab_range(int device, const float *in_dev, const 
     hipStream_t st = as_stream(stream);
     tomo_prof_scope prof(PROF_PDTV, st, 1);
     const int v = (g_variant_pdtv == 0 || g_variant_pdtv == 3) ? g_variant_pdtv : 2;  // slabs always run the per-wave-halo kernel
-    return half ? pd_pair_launch<__half>(a, methodTV, nonneg, v, st) : pd_pair_launch<float>(a, methodTV, nonneg, v, st);
+    return half ? pd_multi_launch<__half>(a, 2, methodTV, nonneg, v, st) : pd_multi_launch<float>(a, 2, methodTV, nonneg, v, st);
 }
 
 extern "C" int tomo_roftv(int device, const float *in_dev, float *out_dev, int dx, int dy, int dz, int nd,
