@@ -108,6 +108,28 @@ int tomo_bp3d(tomo_ctx *ctx, int subset, const float *sino_dev, float *vol_dev, 
 int tomo_fp3d_residual(tomo_ctx *ctx, int subset, const float *vol_dev, const float *b_dev,
                        const float *w_dev, int gathered, int fidelity, float *res_dev, void *stream);
 
+/* ---------------------------------------------------------------- ring-artefact data terms (BASELINE configs[4])
+ * Not in this reference version (supp/dicts.py:85-88 accepts LS / PWLS / KL only); they are documented for its removed
+ * RecToolsIR class: keys ringGH_lambda / ringGH_accelerate (Group-Huber) and data fidelity "SWLS" + beta_SWLS
+ * (docs/source/tutorials/real_data_recon.rst:100-151), models in docs/Kazantsev_CT_20.pdf Table III:
+ *   Group-Huber  min_s 1/2 ||s - L^T r||^2 + lambda ||s||_1,  L = (I (x) 1)/sqrt(m2): one offset per detector pixel,
+ *                constant over the angles; SWLS: W_s = W - W 1 (1^T W 1 + beta)^-1 1^T W per detector pixel.
+ * Parity for these entry points is formula-level only (oracle/tomo_oracle.py fista(..., ring=...)).
+ * tomo_fp3d_residual_ring: res = (A_s x - b_s) + ring_scale * r_x[z,u]   (r_x: [nz][nu], broadcast over the angles)
+ * tomo_ring_gh_reduce    : vec[z,u] = sum_a res[z,a,u] (ascending a); r_out = r_x - l_inv*vec; then, if w_full_dev is
+ *                          given, res[z,a,u] *= w_full[z, src[a], u] in place (PWLS weights after the offset step)
+ * tomo_swls_apply        : res_a <- w_a res_a - w_a (sum_a w_a res_a)/(sum_a w_a + beta) per detector pixel
+ * tomo_ring_gh_update    : r <- soft(r, lambda); r_x = r + beta (r - r_old); r_old <- r     (count = nz*nu)
+ * src_dev: int32 [na_s], the subset's indices into the full sinogram's angle axis. */
+int tomo_fp3d_residual_ring(tomo_ctx *ctx, int subset, const float *vol_dev, const float *b_full_dev,
+                            const float *ring_dev, float ring_scale, float *res_dev, void *stream);
+int tomo_ring_gh_reduce(float *res_dev, const float *w_full_dev, const int *src_dev, int nz, int na_s, int na_full,
+                        int nu, const float *rx_dev, float l_inv, float *r_out_dev, void *stream);
+int tomo_swls_apply(float *res_dev, const float *w_full_dev, const int *src_dev, int nz, int na_s, int na_full, int nu,
+                    float beta, void *stream);
+int tomo_ring_gh_update(float *r_dev, float *r_old_dev, float *rx_dev, float lambda, float beta, size_t count,
+                        void *stream);
+
 /* tomo_bp3d_fista: x_out = P+( x_t - l_inv * A_s^T res )            methodsIR_CuPy.py:463-468
  *   nonneg != 0 applies the max(.,0) projection.  x_out may alias x_t. */
 int tomo_bp3d_fista(tomo_ctx *ctx, int subset, const float *res_dev, const float *xt_dev,

@@ -326,15 +326,31 @@ def grad_data_term(P, x, b_sub, subset, fidelity="LS", w_sub=None):
     return P.bp(res.astype(np.float32, copy=False), subset)
 
 
-def fista(P: Projector, b, iterations, lipschitz_const, nonnegativity=False, reg=None, fidelity="LS", x0=None):
-    """methodsIR_CuPy.py:438-475 (b already padded, canonical [detY, angles, detX] layout)."""
+def fista(P: Projector, b, iterations, lipschitz_const, nonnegativity=False, reg=None, fidelity="LS", x0=None,
+          ring=None, beta_swls=0.1):
+    """methodsIR_CuPy.py:438-475 (b already padded, canonical [detY, angles, detX] layout).
+
+    Ring-artefact data terms (NOT in this reference version -- supp/dicts.py:85-88 knows LS / PWLS / KL only; parity for
+    them is formula-level, unpinned): documented for the reference's removed RecToolsIR class in
+    docs/source/tutorials/real_data_recon.rst:100-151 with the models of docs/Kazantsev_CT_20.pdf Table III.
+      * ``ring = {"lambda": l, "accelerate": c}``: Group-Huber, min_s 1/2||s - L^T r||^2 + l||s||_1 with
+        L = (I (x) 1)/sqrt(m2), i.e. one offset per detector pixel [detY, detX], constant over the angles.  Per
+        sub-iteration (the FISTA step on the offsets, as the removed class did it): res = (A_s x_t - b_s) + c * r_x;
+        r = r_x - (1/L) * sum_angles(res) (float32, ascending angle order); PWLS weights are applied to res afterwards;
+        after the image update r = soft(r, l) and r_x = r + ((t_old - 1)/t) (r - r_old).
+      * ``fidelity = "SWLS"``: stripe-weighted least squares, W_s = W - W 1 (1^T W 1 + beta)^-1 1^T W per detector pixel:
+        res_a = w_a res_a - w_a (sum_a w_a res_a)/(sum_a w_a + beta), sums over the sub-iteration's angles."""
     b = np.ascontiguousarray(b, dtype=np.float32)
-    w = pwls_weights(b) if fidelity == "PWLS" else None
+    w = pwls_weights(b) if fidelity in ("PWLS", "SWLS") else None
     L_inv = np.float32(1.0 / lipschitz_const)
     X = np.zeros((P.nz, P.n, P.n), np.float32) if x0 is None else np.array(x0, dtype=np.float32)
     X_t = X.copy()
     t = np.float32(1.0)
     use_os = P.os_number > 1
+    if ring is not None:
+        r = np.zeros((P.nz, P.nu), np.float32)
+        r_x = r.copy()
+        lam, acc = np.float32(ring["lambda"]), np.float32(ring.get("accelerate", 50))
     for _ in range(iterations):
         for s in range(P.os_number):
             X_old, t_old = X, t
@@ -342,7 +358,28 @@ def fista(P: Projector, b, iterations, lipschitz_const, nonnegativity=False, reg
             idx = P.subsets[s] if use_os else slice(None)
             b_s = b[:, idx, :]
             w_s = None if w is None else w[:, idx, :]
-            grad = grad_data_term(P, X_t, b_s, sub, fidelity, w_s)
+            if ring is not None or fidelity == "SWLS":
+                res = P.fp(X_t, sub) - b_s
+                if ring is not None:
+                    r_old = r
+                    res = res + (acc * r_x)[:, None, :]
+                    vec = np.zeros((P.nz, P.nu), np.float32)
+                    for a in range(res.shape[1]):
+                        vec = vec + res[:, a, :]
+                    r = r_x - L_inv * vec
+                    if fidelity == "PWLS":
+                        res = res * w_s
+                else:
+                    wr = np.zeros((P.nz, P.nu), np.float32)
+                    ws = np.zeros((P.nz, P.nu), np.float32)
+                    for a in range(res.shape[1]):
+                        wr = wr + w_s[:, a, :] * res[:, a, :]
+                        ws = ws + w_s[:, a, :]
+                    q = wr / (ws + np.float32(beta_swls))
+                    res = w_s * res - w_s * q[:, None, :]
+                grad = P.bp(np.ascontiguousarray(res, dtype=np.float32), sub)
+            else:
+                grad = grad_data_term(P, X_t, b_s, sub, fidelity, w_s)
             X = X_t - L_inv * grad
             if nonnegativity:
                 np.maximum(X, 0, out=X)
@@ -351,6 +388,10 @@ def fista(P: Projector, b, iterations, lipschitz_const, nonnegativity=False, reg
             t = np.float32((np.float32(1.0) + np.sqrt(np.float32(1.0) + np.float32(4.0) * t * t)) * np.float32(0.5))
             beta = np.float32((t_old - np.float32(1.0)) / t)
             X_t = X + beta * (X - X_old)
+            if ring is not None:
+                m = np.maximum(np.abs(r) - lam, np.float32(0.0))
+                r = (np.sign(r) * m).astype(np.float32)
+                r_x = r + beta * (r - r_old)
     return X
 
 

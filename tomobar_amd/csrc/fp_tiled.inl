@@ -20,6 +20,8 @@ struct FpTiledArgs {
     int nz, n, nu, na, na_full;
     float *out;
     const float *b, *w;
+    const float *ring;       // Group-Huber offsets r_x [nz][nu] added to the residual (null: none)
+    float ring_scale;        // ringGH_accelerate
     int fidelity, gathered;
     int wpitch;              // LDS pitch (float4 units) per staged row, <= 256 * passes <= 1024
     int nut, ngroups, nzb;   // detector tiles, angle groups, slice quads
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
                     val = (a.fidelity == TOMO_FID_KL) ? 1.0f - qv : qv;
                 } else {
                     val = val - bv;
+                    if (a.ring) val = val + a.ring_scale * a.ring[(size_t)z * a.nu + iu];
                     if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
                 }
             }
@@ -346,6 +349,7 @@ __global__ __launch_bounds__(BT) void fp_tiled_sync_kernel(FpTiledArgs a, int kc
                     val = (a.fidelity == TOMO_FID_KL) ? 1.0f - qv : qv;
                 } else {
                     val = val - bv;
+                    if (a.ring) val = val + a.ring_scale * a.ring[(size_t)z * a.nu + iu];
                     if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
                 }
             }

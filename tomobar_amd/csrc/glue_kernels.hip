@@ -3,6 +3,8 @@
 // ufunc launches produce (methodsIR_CuPy.py:463-475,545-566); fmaf appears only where stated.
 #include "tomo_common.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int EW_BLOCK = 256;
@@ -171,6 +173,61 @@ int reduce_host(const float *x, const float *y, size_t n, double *out, void *str
     return TOMO_OK;
 }
 
+// ---- ring-artefact data terms: reductions over the angles of one (ordered-subset) residual, one thread per detector
+//      pixel (z, u), angles summed in ascending order (deterministic; the oracle sums in the same order)
+// Group-Huber: vec = sum_a res[z,a,u];  r = r_x - l_inv * vec;  then the PWLS weights are applied to res in place
+__global__ __launch_bounds__(256) void ring_gh_reduce_kernel(float *res, const float *w_full, const int *src, int nz, int na_s,
+                                                             int na_full, int nu, const float *r_x, float l_inv, float *r_out)
+{
+    const size_t total = (size_t)nz * nu;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t z = i / nu, u = i % nu;
+        float vec = 0.0f;
+        float *col = res + (z * na_s) * nu + u;
+        for (int a = 0; a < na_s; ++a) {
+            const float v = col[(size_t)a * nu];
+            vec = vec + v;
+            if (w_full) col[(size_t)a * nu] = v * w_full[(z * na_full + src[a]) * nu + u];
+        }
+        r_out[i] = r_x[i] - l_inv * vec;
+    }
+}
+
+// Stripe-weighted least squares: res_a <- w_a res_a - w_a (sum_a w_a res_a) / (sum_a w_a + beta)
+__global__ __launch_bounds__(256) void swls_kernel(float *res, const float *w_full, const int *src, int nz, int na_s, int na_full,
+                                                   int nu, float beta)
+{
+    const size_t total = (size_t)nz * nu;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t z = i / nu, u = i % nu;
+        float *col = res + (z * na_s) * nu + u;
+        float wr = 0.0f, ws = 0.0f;
+        for (int a = 0; a < na_s; ++a) {
+            const float wa = w_full[(z * na_full + src[a]) * nu + u];
+            wr = wr + wa * col[(size_t)a * nu];
+            ws = ws + wa;
+        }
+        const float q = wr / (ws + beta);
+        for (int a = 0; a < na_s; ++a) {
+            const float wa = w_full[(z * na_full + src[a]) * nu + u];
+            col[(size_t)a * nu] = wa * col[(size_t)a * nu] - wa * q;
+        }
+    }
+}
+
+// soft threshold + momentum of the offsets:  r <- sign(r) max(|r| - lambda, 0);  r_x = r + beta (r - r_old);  r_old <- r
+__global__ __launch_bounds__(256) void ring_gh_update_kernel(float *r, float *r_old, float *r_x, float lambda, float beta, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = r[i];
+        const float m = fmaxf(fabsf(v) - lambda, 0.0f);
+        const float t = v > 0.0f ? m : (v < 0.0f ? -m : 0.0f);
+        r[i] = t;
+        r_x[i] = t + beta * (t - r_old[i]);
+        r_old[i] = t;
+    }
+}
+
 // ---- pre/post
 __global__ void pad_edge_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int nu0, int pad)
 {
@@ -297,6 +354,40 @@ extern "C" int tomo_pwls_max(const float *b, size_t count, float *out_host, void
 extern "C" int tomo_pwls_weights_scaled(const float *b, float *w, size_t count, float wmax, void *stream)
 {
     return ew_launch<1, 1>(b, nullptr, nullptr, w, nullptr, count, stream, PwlsF{wmax});
+}
+
+extern "C" int tomo_ring_gh_reduce(float *res_dev, const float *w_full_dev, const int *src_dev, int nz, int na_s, int na_full,
+                                   int nu, const float *rx_dev, float l_inv, float *r_out_dev, void *stream)
+{
+    TOMO_REQUIRE(res_dev && rx_dev && r_out_dev && nz > 0 && na_s >= 0 && nu > 0, "bad ring-term arguments");
+    TOMO_REQUIRE(w_full_dev == nullptr || src_dev != nullptr, "weights need the subset's angle index table");
+    const size_t total = (size_t)nz * nu;
+    ring_gh_reduce_kernel<<<(unsigned)std::min<size_t>((total + 255) / 256, 4096), 256, 0, as_stream(stream)>>>(
+        res_dev, w_full_dev, src_dev, nz, na_s, na_full, nu, rx_dev, l_inv, r_out_dev);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
+extern "C" int tomo_swls_apply(float *res_dev, const float *w_full_dev, const int *src_dev, int nz, int na_s, int na_full, int nu,
+                               float beta, void *stream)
+{
+    TOMO_REQUIRE(res_dev && w_full_dev && src_dev && nz > 0 && na_s >= 0 && nu > 0, "bad SWLS arguments");
+    const size_t total = (size_t)nz * nu;
+    swls_kernel<<<(unsigned)std::min<size_t>((total + 255) / 256, 4096), 256, 0, as_stream(stream)>>>(
+        res_dev, w_full_dev, src_dev, nz, na_s, na_full, nu, beta);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
+extern "C" int tomo_ring_gh_update(float *r_dev, float *r_old_dev, float *rx_dev, float lambda, float beta, size_t count,
+                                   void *stream)
+{
+    TOMO_REQUIRE(r_dev && r_old_dev && rx_dev, "NULL ring-term pointer");
+    if (count == 0) return TOMO_OK;
+    ring_gh_update_kernel<<<(unsigned)std::min<size_t>((count + 255) / 256, 4096), 256, 0, as_stream(stream)>>>(
+        r_dev, r_old_dev, rx_dev, lambda, beta, count);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
 }
 
 extern "C" int tomo_pad_edge(const float *in, float *out, int rows, int nu0, int pad, void *stream)

@@ -268,6 +268,8 @@ struct FpArgs {
     float *out;              // [nz][na][nu]
     const float *b;          // residual epilogue: full sinogram [nz][na_full][nu] (null = plain FP)
     const float *w;          // PWLS weights, full sinogram (may be null)
+    const float *ring;       // Group-Huber offsets [nz][nu] (may be null)
+    float ring_scale;
     int fidelity;
     int gathered;            // bit0: b is the gathered subset, bit1: w is
 };
@@ -341,6 +343,7 @@ __global__ __launch_bounds__(256) void fp_march_kernel(FpArgs a)
                 val = (a.fidelity == TOMO_FID_KL) ? 1.0f - q : q;
             } else {
                 val = val - bv;
+                if (a.ring) val = val + a.ring_scale * a.ring[(size_t)z * a.nu + iu];
                 if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
             }
         }
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256) void fp_march_kernel(FpArgs a)
 #include "fp_tiled.inl"
 
 int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const float *w, int gathered, int fidelity,
-           float *out, void *stream)
+           float *out, void *stream, const float *ring = nullptr, float ring_scale = 0.0f)
 {
     TOMO_REQUIRE(ctx != nullptr, "ctx is NULL");
     TOMO_REQUIRE(vol != nullptr && out != nullptr, "NULL data pointer");
@@ -378,6 +381,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
     a.tab = ctx->dev_table + s.table_offset;
     a.nz = ctx->nz; a.n = ctx->n; a.nu = ctx->nu; a.na = s.size; a.na_full = ctx->na;
     a.out = out; a.b = b; a.w = w; a.fidelity = fidelity; a.gathered = gathered;
+    a.ring = ring; a.ring_scale = ring_scale;
     dim3 grid(ceil_div(ctx->nu, 256), s.size, ceil_div(ctx->nz, 4));
     tomo_prof_scope prof(PROF_FP, st, 1);
     ctx->last_fp_path.clear();
@@ -438,6 +442,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 t.n_class = nc;
                 t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
                 t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
+                t.ring = ring; t.ring_scale = ring_scale;
                 t.wpitch = wp;
                 t.nut = nut_w;
                 t.ngroups = ceil_div(nc, FP_A);
@@ -480,6 +485,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 t.n_class = nc;
                 t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
                 t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
+                t.ring = ring; t.ring_scale = ring_scale;
                 t.wpitch = s.wbound[c];
                 const int passes = ceil_div(t.wpitch, 256);           // 1..5 in the pipelined kernel
                 // (items per thread, double buffer) per pass count -- keep in step with FP_TILED_LAUNCH below
@@ -575,6 +581,13 @@ extern "C" int tomo_fp3d_residual(tomo_ctx *ctx, int subset, const float *vol_de
     TOMO_REQUIRE(fidelity != TOMO_FID_PWLS || w_full_dev != nullptr, "PWLS needs the weights");
     return fp_run(ctx, subset, vol_dev, b_full_dev, fidelity == TOMO_FID_PWLS ? w_full_dev : nullptr, gathered,
                   fidelity, res_dev, stream);
+}
+
+extern "C" int tomo_fp3d_residual_ring(tomo_ctx *ctx, int subset, const float *vol_dev, const float *b_full_dev,
+                                       const float *ring_dev, float ring_scale, float *res_dev, void *stream)
+{
+    TOMO_REQUIRE(b_full_dev != nullptr && ring_dev != nullptr, "projection data / ring offset pointer is NULL");
+    return fp_run(ctx, subset, vol_dev, b_full_dev, nullptr, 0, TOMO_FID_LS, res_dev, stream, ring_dev, ring_scale);
 }
 
 extern "C" int tomo_bp3d(tomo_ctx *ctx, int subset, const float *sino_dev, float *vol_dev, void *stream)

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void pd_pervoxel_kernel(PdArgs a)
 static int pd_iters_per_launch(int variant, int half)
 {
     if (variant == 21) return 3;
-    if (variant == 0 && !half) return 3;
+    if ((variant == 0 || (variant >= 24 && variant <= 27)) && !half) return 3;
     return 2;
 }
 
@@ -176,6 +176,10 @@ int pd_multi_launch(const PdArgs &a, int k, int methodTV, int nonneg, int varian
     constexpr bool F32 = sizeof(T) == 4;
 #define PD_XK(NN, AN)                                                                                   \
     (k == 3 ? (variant == 21 ? pd_zmarch_xk_launch<T, NN, AN, false, 3, 4, 2, 2>(a, st)                  \
+               : variant == 24 ? pd_zmarch_xk_launch<T, NN, AN, F32, 3, 3, 2, 4>(a, st)                  \
+               : variant == 25 ? pd_zmarch_xk_launch<T, NN, AN, F32, 3, 3, 1, 4>(a, st)                  \
+               : variant == 26 ? pd_zmarch_xk_launch<T, NN, AN, F32, 3, 3, 1, 8>(a, st)                  \
+               : variant == 27 ? pd_zmarch_xk_launch<T, NN, AN, F32, 3, 3, 4, 2>(a, st)                  \
                              : pd_zmarch_xk_launch<T, NN, AN, F32, 3, 3, 2, 2>(a, st))                   \
      : variant == 10 ? pd_tile_launch<T, NN, AN, false, 4, 1, 8>(a, st)                                  \
      : variant == 11 ? pd_tile_launch<T, NN, AN, true, 4, 1, 8>(a, st)                                   \

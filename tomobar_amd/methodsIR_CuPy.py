@@ -127,7 +127,7 @@ class RecToolsIRCuPy:
         if x0 is None:
             x0 = self._new_vol(1.0 if method_run == "OSEM" else 0.0)
         use_os = self.OS_number > 1
-        w = ops.pwls_weights(d["projection_data"], self.slab) if _data_["data_fidelity"] in ["PWLS"] else None
+        w = ops.pwls_weights(d["projection_data"], self.slab) if _data_["data_fidelity"] in ["PWLS", "SWLS"] else None
         return (d, a, r, x0, w, use_os)
 
     # ------------------------------------------------------------------ power method
@@ -168,6 +168,18 @@ class RecToolsIRCuPy:
         nonneg = bool(a["nonnegativity"])
         has_prox = r["method"] is not None
 
+        # ring-artefact data terms (BASELINE configs[4]; not in this reference version, see supp/dicts.py here):
+        # Group-Huber offsets r [detY, detX] (one per detector pixel, constant over the angles) and / or SWLS weighting
+        ring_lambda = d.get("ringGH_lambda")
+        use_ring = ring_lambda is not None
+        use_swls = fid == "SWLS"
+        if use_ring:
+            ring_acc = float32(d["ringGH_accelerate"])
+            r_shape = (A.nz, A.nu)
+            r_cur = torch.zeros(r_shape, dtype=torch.float32, device=A._device)
+            r_old = torch.zeros(r_shape, dtype=torch.float32, device=A._device)
+            r_x = torch.zeros(r_shape, dtype=torch.float32, device=A._device)
+
         t = float32(1.0)
         X = x0                      # doubles as X_old at the start of every sub-iteration
         X_t = x0.clone()
@@ -181,7 +193,15 @@ class RecToolsIRCuPy:
                 t_old = t
                 if sub not in res:
                     res[sub] = torch.empty(A.sino_shape(sub), dtype=torch.float32, device=A._device)
-                A.residual(X_t, b, w, fid, sub, res[sub])
+                if use_ring:
+                    # res = (A_s X_t - b_s) + accelerate * r_x ;  r = r_x - (1/L) sum_angles res ;  then the PWLS weights
+                    A.residual_ring(X_t, b, r_x, ring_acc, sub, res[sub])
+                    A.ring_reduce(res[sub], w if fid == "PWLS" else None, r_x, L_inv, sub, r_cur)
+                elif use_swls:
+                    A.residual(X_t, b, None, "LS", sub, res[sub])
+                    A.swls_apply(res[sub], w, float32(d["beta_SWLS"]), sub)
+                else:
+                    A.residual(X_t, b, w, fid, sub, res[sub])
                 t = float32((float32(1.0) + np.sqrt(float32(1.0) + float32(4.0) * t * t)) * float32(0.5))
                 beta = float32((t_old - float32(1.0)) / t)
                 if not has_prox:
@@ -192,6 +212,9 @@ class RecToolsIRCuPy:
                     prox_regul(self, X_grad, r, out=X_prox)
                     ops.momentum(X_prox, X, X_t, beta)
                     X, X_prox = X_prox, X
+                if use_ring:
+                    # r <- soft(r, lambda) ;  r_x = r + beta (r - r_old)
+                    A.ring_update(r_cur, r_old, r_x, float32(ring_lambda), beta)
         return self._finalise(X, a)
 
     # ------------------------------------------------------------------ ADMM

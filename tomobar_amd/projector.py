@@ -207,6 +207,41 @@ class HipTools3D:
                                                ops.stream_ptr(vol)))
         return out
 
+    # ---- ring-artefact data terms (Group-Huber offsets / stripe-weighted least squares); see include/tomo_mi355x.h
+    def _src_table(self, os_index):
+        """int32 device table of the subset's indices into the full angle axis (cached)."""
+        key = self._sub(os_index)
+        tabs = self.__dict__.setdefault("_src_tables", {})
+        if key not in tabs:
+            idx = np.arange(self.na) if key < 0 else self.subset_indices(key)
+            tabs[key] = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(self._device)
+        return tabs[key]
+
+    def residual_ring(self, vol, b, r_x, accelerate, os_index, out):
+        """out = (A_s vol - b_s) + accelerate * r_x[z, u]  (LS residual with the Group-Huber offsets added)."""
+        with torch.cuda.device(self._device):
+            L.check(L.lib().tomo_fp3d_residual_ring(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(b), ops.ptr(r_x),
+                                                    float(accelerate), ops.ptr(out), ops.stream_ptr(vol)))
+        return out
+
+    def ring_reduce(self, res, w, r_x, l_inv, os_index, r_out):
+        """r_out = r_x - l_inv * sum_angles(res); afterwards res *= w_s in place when PWLS weights are given."""
+        src = self._src_table(os_index)
+        with torch.cuda.device(self._device):
+            L.check(L.lib().tomo_ring_gh_reduce(ops.ptr(res), ops.ptr(w), ops.ptr(src), self.nz, int(src.numel()), self.na,
+                                                self.nu, ops.ptr(r_x), float(l_inv), ops.ptr(r_out), ops.stream_ptr(res)))
+
+    def swls_apply(self, res, w, beta, os_index):
+        src = self._src_table(os_index)
+        with torch.cuda.device(self._device):
+            L.check(L.lib().tomo_swls_apply(ops.ptr(res), ops.ptr(w), ops.ptr(src), self.nz, int(src.numel()), self.na,
+                                            self.nu, float(beta), ops.stream_ptr(res)))
+
+    def ring_update(self, r, r_old, r_x, lam, beta):
+        with torch.cuda.device(self._device):
+            L.check(L.lib().tomo_ring_gh_update(ops.ptr(r), ops.ptr(r_old), ops.ptr(r_x), float(lam), float(beta),
+                                                r.numel(), ops.stream_ptr(r)))
+
     def grad_step(self, res, x_t, x_out, l_inv, nonneg, os_index):
         with torch.cuda.device(self._device):
             L.check(L.lib().tomo_bp3d_fista(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(x_t), ops.ptr(x_out),

@@ -52,9 +52,21 @@ def dicts_check(self, _data_: dict, _algorithm_: Optional[dict] = None, _regular
 
     if _data_.get("data_fidelity") is None:
         _data_["data_fidelity"] = "LS"
-    if _data_["data_fidelity"] not in {"LS", "PWLS", "KL"}:
-        raise ValueError("_data_['data_fidelity'] should be provided as 'LS', 'PWLS', 'KL'.")
+    # "SWLS" (stripe-weighted least squares) and the Group-Huber keys below are the ring-artefact data terms of the
+    # reference's removed RecToolsIR class (docs/source/tutorials/real_data_recon.rst:100-151); the reference's current
+    # dicts_check knows LS / PWLS / KL only
+    if _data_["data_fidelity"] not in {"LS", "PWLS", "KL", "SWLS"}:
+        raise ValueError("_data_['data_fidelity'] should be provided as 'LS', 'PWLS', 'KL' (or 'SWLS').")
     self.data_fidelity = _data_["data_fidelity"]
+    _data_.setdefault("ringGH_lambda", None)        # Group-Huber offsets: off unless a threshold is given
+    _data_.setdefault("ringGH_accelerate", 50)
+    _data_.setdefault("beta_SWLS", 0.1)
+    if _data_["ringGH_lambda"] is not None and _data_["data_fidelity"] not in {"LS", "PWLS"}:
+        raise ValueError("the Group-Huber ring term (ringGH_lambda) combines with the 'LS' and 'PWLS' data fidelities only")
+    if _data_["data_fidelity"] == "SWLS" and method_run != "FISTA":
+        raise ValueError("the 'SWLS' data fidelity is available in FISTA only")
+    if _data_["ringGH_lambda"] is not None and method_run != "FISTA":
+        raise ValueError("the Group-Huber ring term (ringGH_lambda) is available in FISTA only")
 
     if self.OS_number > 1 and method_run in _NO_OS_METHODS:
         raise NameError(

@@ -7,8 +7,13 @@ from tomobar_amd import ops
 from tomobar_amd.regularisersCuPy import PD_TV_cupy
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 variants = [int(v) for v in sys.argv[2:]] or [0, 2, 10, 11]
-ROUNDS, IT = 5, 8
-vol = torch.rand((N, N, N), device="cuda")
+ROUNDS, IT = 5, 12
+DATA = os.environ.get("PD_DATA", "rand")
+if DATA == "phantom":   # the bench's kind of volume: piecewise-constant phantom + mild noise
+    import bench
+    vol = bench.phantom_slab(N, N, 0, N, torch.device("cuda")) + 0.02 * torch.randn((N, N, N), device="cuda")
+else:
+    vol = torch.rand((N, N, N), device="cuda")
 out = torch.empty_like(vol)
 res = {}
 for rnd in range(ROUNDS):
@@ -20,7 +25,7 @@ for rnd in range(ROUNDS):
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            PD_TV_cupy(vol, 0.01, IT, 0, 1, 12.0, 0, half, out=out)
+            PD_TV_cupy(vol, 5e-4 if DATA == "phantom" else 0.01, IT, 0, 1, 12.0, 0, half, out=out)
             e1.record(); torch.cuda.synchronize()
             res.setdefault((v, half), []).append(e0.elapsed_time(e1) / IT)
 for (v, half), ts in res.items():
