@@ -278,6 +278,14 @@ int tomo_set_variant(const char *kernel, int variant);
 int tomo_profile_enable(int on);
 int tomo_profile_read(const char *kernel, long long *launches, double *total_ms);
 
+/* ---------------------------------------------------------------- host (CPU) 2D plumbing, BASELINE configs[0]
+ * RecToolsDIR(..., device_projector="cpu") of the reference runs ASTRA's CPU `line` projector / `BP` algorithm
+ * (tomobar/methodsDIR.py:71-175, astra_base.py:224-232,310-372).  These two entry points take HOST pointers and need no
+ * GPU: img [n][n], sino [na][nu], angles in radians, scalar CoR (the reference's CPU path rejects a non-zero one,
+ * astra_base.py:150-153).  Same operator model and float32 arithmetic as tomo_bp3d / tomo_fp3d. */
+int tomo_host_bp2d(const float *sino_host, float *img_host, int n, int nu, int na, const double *angles_host, double cor);
+int tomo_host_fp2d(const float *img_host, float *sino_host, int n, int nu, int na, const double *angles_host, double cor);
+
 #ifdef __cplusplus
 }
 #endif

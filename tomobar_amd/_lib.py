@@ -83,6 +83,8 @@ SIGNATURES = {
     "tomo_roftv_iter_slab_range": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "tomo_fbp_filter": (_i, [_i, _vp, _sz, _i, _f, _f, _vp]),
     "tomo_fourier_inv": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _f, _i, _vp]),
+    "tomo_host_bp2d": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_d), _d]),
+    "tomo_host_fp2d": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_d), _d]),
     "tomo_set_variant": (_i, [C.c_char_p, _i]),
     "tomo_profile_enable": (_i, [_i]),
     "tomo_profile_read": (_i, [C.c_char_p, C.POINTER(C.c_longlong), C.POINTER(_d)]),
