@@ -11,10 +11,24 @@
 // Row slots r in [-K, RY+K) are array index r+K; every array is declared at the full height NR and the unrolled code
 // only ever touches the slots a stage needs (the rest is removed by the compiler).
 // Arithmetic per voxel and iteration is exactly that of the single-iteration kernels, whatever K is.
-template <typename T, bool NONNEG, bool ANISO, bool FAST, int K, int RY, int WX, int WY>
+// LAG: the state a stage hands over ACROSS steps (P^{n+s}(t-s) for stages s >= 1 and the Input planes t-1 .. t-K+1) lives
+// in LDS instead of registers: every thread owns private slots [slot][thread] (conflict-free, no barrier needed), read
+// back exactly where it is consumed.  That is what lets K = 3 run with RY = 4 rows at two waves per SIMD (46 values per
+// lane would otherwise push the kernel past 256 registers): 45 row loads / 21 dual rows per 12 output-row-iterations
+// instead of 40 / 18 per 9.
+constexpr int xk_dual_rows(int K, int RY, int s) { return RY + 2 * (K - s) - 1; }
+constexpr int xk_p_base(int K, int RY, int s) { return s <= 1 ? 0 : xk_p_base(K, RY, s - 1) + 3 * xk_dual_rows(K, RY, s - 1); }
+constexpr int xk_in_rows(int K, int RY) { return RY + 2 * (K - 2); }
+constexpr int xk_lag_slots(int K, int RY) { return xk_p_base(K, RY, K) + K * xk_in_rows(K, RY); }
+
+template <typename T, bool NONNEG, bool ANISO, bool FAST, int K, int RY, int WX, int WY, bool LAG = false>
 __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, int gx, int gy, int gy_per_xcd)
 {
     constexpr int NR = RY + 2 * K;
+    constexpr int NT = 64 * WX * WY;
+    constexpr int IN_BASE = xk_p_base(K, RY, K), IN_ROWS = xk_in_rows(K, RY);
+    __shared__ float lag[LAG ? xk_lag_slots(K, RY) : 1][LAG ? NT : 1];
+    const int tid = (int)threadIdx.x;
     int j = (int)blockIdx.x >> 3;
     const int xcd = (int)blockIdx.x & 7;
     const int xb = j % gx;
@@ -64,6 +78,11 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
             In[s][i] = 0.0f; c3[s][i] = 0.0f;
         }
 
+    if (LAG) {
+#pragma unroll
+        for (int q = 0; q < xk_lag_slots(K, RY); ++q) lag[q][tid] = 0.0f;
+    }
+
     // stage s starts K-s planes below the first output plane (warm-up planes rebuild the carries and the rings)
     const int zA = max(zc0 - K, 0);
     const int tEnd = min(zc1, dz) + K - 2;  // the last stage must reach plane zc1-1
@@ -100,6 +119,11 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
             const float *ip = a.in + sz * t;
 #pragma unroll
             for (int i = 1; i < NR - 1; ++i) In[0][i] = ldf(ip, off[i]);
+            if (LAG) {  // Input(t) for the later stages: ring slot t mod K
+                const int q = t % K;
+#pragma unroll
+                for (int i = 2; i < 2 + IN_ROWS; ++i) lag[IN_BASE + q * IN_ROWS + (i - 2)][tid] = In[0][i];
+            }
         }
 #pragma unroll
         for (int s = 0; s < K; ++s) {
@@ -110,11 +134,19 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
             for (int i = 0; i < NR; ++i) Vn[i] = 0.0f;
             if (act) {
                 const bool p_last = (p == dz - 1) && a.last_is_edge;
-                if (s > 0) {
+                if (s > 0 && !LAG) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
 #pragma unroll
                         for (int i = 0; i < NR; ++i) Pw[c][i] = (sizeof(T) == 2) ? DualIO<T>::rt(Pp[s][c][i]) : Pp[s][c][i];
+                }
+                float InS[NR];  // Input(p) of this stage
+#pragma unroll
+                for (int i = 0; i < NR; ++i) InS[i] = In[s][i];
+                if (LAG && s > 0) {
+                    const int q = (t + K - s) % K;
+#pragma unroll
+                    for (int r = -(K - s - 1); r <= RY + (K - s - 1) - 1; ++r) InS[r + K] = lag[IN_BASE + q * IN_ROWS + (r + K - 2)][tid];
                 }
                 // ---------------- duals, rows -(K-s) .. RY+(K-s)-2
 #pragma unroll
@@ -151,7 +183,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
                     float div = (-(Pw[0][i] - px)) + (-(Pw[1][i] - py));
                     div = div + (-(Pw[2][i] - pz));
                     const float u = (s == 0) ? U0c[i] : Ur[s][1][i];
-                    const float uo = pd_primal_t<FAST>(u, In[s][i], div, a.tau, a.lt, a.inv1lt, a.theta, NONNEG);
+                    const float uo = pd_primal_t<FAST>(u, InS[i], div, a.tau, a.lt, a.inv1lt, a.theta, NONNEG);
                     Vn[i] = uo;
                     if (s == K - 1) {
                         if (emit_plane && emit_lane && y < dy) {
@@ -178,23 +210,40 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
                     Ur[s + 1][2][i] = Vn[i];
                 }
                 // P^{n+s+1}(p) is stage s+1's input at the NEXT step (stage s+1 of this step reads the previous hand-over)
+                if (!LAG) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int i = 0; i < NR; ++i) Pnext[s + 1][c][i] = Pw[c][i];
+                } else {
+                    // swap through LDS: fetch what stage s+1 needs NOW (last step's hand-over), leave this step's behind
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int r = -(K - s - 1); r <= RY + (K - s - 1) - 2; ++r) {
+                            const int i = r + K;
+                            const int slot = xk_p_base(K, RY, s + 1) + c * xk_dual_rows(K, RY, s + 1) + (i - (s + 1));
+                            const float nxt = Pw[c][i];
+                            const float old = lag[slot][tid];
+                            lag[slot][tid] = nxt;
+                            Pw[c][i] = (sizeof(T) == 2) ? DualIO<T>::rt(old) : old;
+                        }
+                }
+            }
+        }
+        if (!LAG) {
+#pragma unroll
+            for (int s = 1; s < K; ++s)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
-                    for (int i = 0; i < NR; ++i) Pnext[s + 1][c][i] = Pw[c][i];
-            }
+                    for (int i = 0; i < NR; ++i) Pp[s][c][i] = Pnext[s][c][i];
+            // ---------------- rotate the Input ring
+#pragma unroll
+            for (int s = K - 1; s > 0; --s)
+#pragma unroll
+                for (int i = 0; i < NR; ++i) In[s][i] = In[s - 1][i];
         }
-#pragma unroll
-        for (int s = 1; s < K; ++s)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int i = 0; i < NR; ++i) Pp[s][c][i] = Pnext[s][c][i];
-        // ---------------- rotate the Input ring and the stage-0 plane
-#pragma unroll
-        for (int s = K - 1; s > 0; --s)
-#pragma unroll
-            for (int i = 0; i < NR; ++i) In[s][i] = In[s - 1][i];
         if (act0) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) U0c[i] = U0n[i];
@@ -202,7 +251,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
     }
 }
 
-template <typename T, bool NONNEG, bool ANISO, bool FAST, int K, int RY, int WX, int WY>
+template <typename T, bool NONNEG, bool ANISO, bool FAST, int K, int RY, int WX, int WY, bool LAG = false>
 static int pd_zmarch_xk_launch(PdArgs a, hipStream_t st)
 {
     const int nout = a.out_end - a.out_begin;
@@ -219,6 +268,6 @@ static int pd_zmarch_xk_launch(PdArgs a, hipStream_t st)
     a.inv1lt = 1.0f / (1.0f + a.lt);
     const long blocks = 8L * gx * gy_per_xcd * chunks;
     if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one PD_TV launch");
-    pd_zmarch_xk_kernel<T, NONNEG, ANISO, FAST, K, RY, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd);
+    pd_zmarch_xk_kernel<T, NONNEG, ANISO, FAST, K, RY, WX, WY, LAG><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd);
     return TOMO_OK;
 }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void pd_pervoxel_kernel(PdArgs a)
 #include "pd_zmarch_xk.inl"
 
 // Several iterations in one pass through HBM (3D).  `k` = iterations of this launch (2 or 3).
-//   variant 0 (shipped): float32 duals: relaxed arithmetic, k = 3 -> pd_zmarch_xk<K=3, 3 rows, 2x2 waves>,
+//   variant 0 (shipped): float32 duals: relaxed arithmetic, k = 3 -> pd_zmarch_xk<K=3, 4 rows, 2x2 waves, LDS lag>,
 //                        k = 2 -> pd_zmarch_x2<2x4 waves>;  binary16 duals: exact arithmetic, k = 2 only (one flipped
 //                        binary16 rounding is 5e-4 of a dual value: relaxed arithmetic cannot hold the 1e-5 parity bar,
 //                        and the exact K = 3 kernel is VALU-bound: 6.4 vs 4.4 ms per iteration)
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void pd_pervoxel_kernel(PdArgs a)
 static int pd_iters_per_launch(int variant, int half)
 {
     if (variant == 21) return 3;
-    if ((variant == 0 || (variant >= 24 && variant <= 27)) && !half) return 3;
+    if (variant == 0 && !half) return 3;
     return 2;
 }
 
@@ -175,12 +175,8 @@ int pd_multi_launch(const PdArgs &a, int k, int methodTV, int nonneg, int varian
 {
     constexpr bool F32 = sizeof(T) == 4;
 #define PD_XK(NN, AN)                                                                                   \
-    (k == 3 ? (variant == 21 ? pd_zmarch_xk_launch<T, NN, AN, false, 3, 4, 2, 2>(a, st)                  \
-               : variant == 24 ? pd_zmarch_xk_launch<T, NN, AN, F32, 3, 3, 2, 4>(a, st)                  \
-               : variant == 25 ? pd_zmarch_xk_launch<T, NN, AN, F32, 3, 3, 1, 4>(a, st)                  \
-               : variant == 26 ? pd_zmarch_xk_launch<T, NN, AN, F32, 3, 3, 1, 8>(a, st)                  \
-               : variant == 27 ? pd_zmarch_xk_launch<T, NN, AN, F32, 3, 3, 4, 2>(a, st)                  \
-                             : pd_zmarch_xk_launch<T, NN, AN, F32, 3, 3, 2, 2>(a, st))                   \
+    (k == 3 ? (variant == 21 ? pd_zmarch_xk_launch<T, NN, AN, false, 3, 4, 2, 2, true>(a, st)            \
+                             : pd_zmarch_xk_launch<T, NN, AN, F32, 3, 4, 2, 2, true>(a, st))             \
      : variant == 10 ? pd_tile_launch<T, NN, AN, false, 4, 1, 8>(a, st)                                  \
      : variant == 11 ? pd_tile_launch<T, NN, AN, true, 4, 1, 8>(a, st)                                   \
      : variant == 20 ? pd_zmarch_xk_launch<T, NN, AN, false, 2, 4, 2, 2>(a, st)                          \
