@@ -220,7 +220,7 @@ int tomo_pdtv_iter_slab(int device, const float *in_dev, const float *u_in_dev, 
                         int has_lo, int has_hi, float sigma, float tau, float lt, float theta,
                         int methodTV, int nonneg, int half, void *stream);
 /* Two PD-TV iterations in one pass on a slab: arrays address [lo_planes + nz_local + hi_planes][dy][dx] with
- * lo_planes, hi_planes in {0, 2}.  Ghost planes that must be valid on entry: U two planes either side; P two planes
+ * lo_planes, hi_planes in {0, 2, 3}.  Ghost planes that must be valid on entry: U two planes either side; P two planes
  * below and the first plane above; Input the nearer plane either side.  Result = two applications of
  * tomo_pdtv_iter_slab with a ghost refresh in between, bit for bit. */
 int tomo_pdtv_pair_slab(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
@@ -234,6 +234,14 @@ int tomo_pdtv_pair_slab_range(int device, const float *in_dev, const float *u_in
                               const void *p_in_dev[3], void *p_out_dev[3], int dx, int dy, int nz_local,
                               int lo_planes, int hi_planes, int z_begin, int z_end, float sigma, float tau,
                               float lt, float theta, int methodTV, int nonneg, int half, void *stream);
+/* K iterations (k = 2 or 3) in one pass on a slab whose arrays carry lo_planes / hi_planes in {0, k..3} ghost planes.
+ * Ghost planes that must be valid on entry: U and P1..3 k planes below, U k planes and P1..3 k-1 planes above, Input
+ * k-1 planes either side.  Result = k applications of tomo_pdtv_iter_slab with ghost refreshes in between, bit for bit.
+ * (Which k a run uses is the host's choice: tomobar_amd/slab.py mirrors tomo_pdtv -- 3 for float32 duals, 2 for binary16.) */
+int tomo_pdtv_multi_slab_range(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
+                               const void *p_in_dev[3], void *p_out_dev[3], int dx, int dy, int nz_local,
+                               int lo_planes, int hi_planes, int z_begin, int z_end, int k, float sigma, float tau,
+                               float lt, float theta, int methodTV, int nonneg, int half, void *stream);
 int tomo_roftv_iter_slab(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
                          int dx, int dy, int nz_local, int lo_planes, int hi_planes,
                          float lambda, float tau, int half, void *stream);

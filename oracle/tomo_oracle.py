@@ -236,9 +236,10 @@ def pd_step_slab(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, has_lo, has_hi, sig
 
 
 def pd_pair_slab(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, lo, hi, sigma, tau, lt, theta, methodTV, nonneg, half,
-                 zr=None):
-    """Two PD_TV iterations on a slab with two-plane ghosts (signature of tomobar_amd.slab._hip_pd_pair), as two
-    applications of orc_pdtv_step: the first one also produces the planes next to the slab that the second one reads."""
+                 zr=None, k=2):
+    """k (2 or 3) PD_TV iterations on a slab whose arrays carry lo / hi ghost planes (0 or >= k) (signature of
+    tomobar_amd.slab._hip_pd_pair), as k applications of orc_pdtv_step: every application but the last also produces the
+    ghost-zone planes the next one reads, so its output range shrinks by one plane per step towards the local planes."""
     import torch
     L = lib()
     fp = C.POINTER(C.c_float)
@@ -246,26 +247,24 @@ def pd_pair_slab(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, lo, hi, sigma, tau,
     L.orc_pdtv_step.restype = None
     planes = nzl + lo + hi
     first_edge, last_edge = (0 if lo else 1), (0 if hi else 1)
-    i_np, u0 = inp.numpy(), u_in.numpy()
     # stale garbage in never-consumed ghost planes must not be NaN for the CPU run: work on sanitised copies
-    i_np = np.nan_to_num(i_np.copy())
-    pin = [np.nan_to_num(np.ascontiguousarray(p.numpy().astype(np.float32))) for p in p_in]
-    u0 = np.nan_to_num(u0.copy())
-    u1 = np.zeros_like(u0)
-    p1 = [np.zeros_like(a) for a in pin]
-    b1, e1 = (1 if lo else 0), (planes - 1 if hi else planes)
-    L.orc_pdtv_step(_fptr(i_np), _fptr(u0), _fptr(u1), _fptr(pin[0]), _fptr(pin[1]), _fptr(pin[2]), _fptr(p1[0]),
-                    _fptr(p1[1]), _fptr(p1[2]), dx, dy, planes, b1, e1, first_edge, last_edge, sigma, tau, lt, theta,
-                    int(bool(methodTV)), int(bool(nonneg)), int(bool(half)))
-    u2 = np.zeros_like(u0)
-    p2 = [np.zeros_like(a) for a in pin]
-    L.orc_pdtv_step(_fptr(i_np), _fptr(u1), _fptr(u2), _fptr(p1[0]), _fptr(p1[1]), _fptr(p1[2]), _fptr(p2[0]),
-                    _fptr(p2[1]), _fptr(p2[2]), dx, dy, planes, lo, lo + nzl, first_edge, last_edge, sigma, tau, lt, theta,
-                    int(bool(methodTV)), int(bool(nonneg)), int(bool(half)))
-    z0, z1 = zr if zr is not None else (0, nzl)  # only these local planes are written (tomo_pdtv_pair_slab_range)
-    u_out[lo + z0:lo + z1] = torch.from_numpy(u2[lo + z0:lo + z1])
+    i_np = np.nan_to_num(inp.numpy().copy())
+    u_cur = np.nan_to_num(u_in.numpy().copy())
+    p_cur = [np.nan_to_num(np.ascontiguousarray(p.numpy().astype(np.float32))) for p in p_in]
+    for j in range(k):
+        shrink = k - 1 - j
+        b = lo - shrink if lo else 0
+        e = lo + nzl + shrink if hi else planes
+        u_nxt = np.zeros_like(u_cur)
+        p_nxt = [np.zeros_like(a) for a in p_cur]
+        L.orc_pdtv_step(_fptr(i_np), _fptr(u_cur), _fptr(u_nxt), _fptr(p_cur[0]), _fptr(p_cur[1]), _fptr(p_cur[2]),
+                        _fptr(p_nxt[0]), _fptr(p_nxt[1]), _fptr(p_nxt[2]), dx, dy, planes, b, e, first_edge, last_edge,
+                        sigma, tau, lt, theta, int(bool(methodTV)), int(bool(nonneg)), int(bool(half)))
+        u_cur, p_cur = u_nxt, p_nxt
+    z0, z1 = zr if zr is not None else (0, nzl)  # only these local planes are written (tomo_pdtv_multi_slab_range)
+    u_out[lo + z0:lo + z1] = torch.from_numpy(u_cur[lo + z0:lo + z1])
     for c in range(3):
-        p_out[c][lo + z0:lo + z1] = torch.from_numpy(p2[c][lo + z0:lo + z1]).to(p_out[c].dtype)
+        p_out[c][lo + z0:lo + z1] = torch.from_numpy(p_cur[c][lo + z0:lo + z1]).to(p_out[c].dtype)
 
 
 def rof_step_slab(inp, u_in, u_out, dx, dy, nzl, lo, hi, lam, tau, half, zr=None):

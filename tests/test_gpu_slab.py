@@ -49,26 +49,25 @@ def test_pdtv_slabs_equal_whole_volume(world, half, variant):
                     dst.copy_(src)
                 for src, dst in zip(hi.initial_send_down(), lo.initial_recv_up()):
                     dst.copy_(src)
-            it = 0
-            while it < iters:
-                if ranges and iters - it >= 2:
-                    args = (sigma, tau, lt, np.float32(1.0), 0, 1)
+            from tomobar_amd.slab import pd_launch_plan
+            args = (sigma, tau, lt, np.float32(1.0), 0, 1)
+            plan = pd_launch_plan(iters, half)   # the launches tomo_pdtv itself makes: 3 + 3 + ... (2 for binary16 duals)
+            for n, k in enumerate(plan):
+                if ranges and k >= 2:
                     for s in states:
                         for z0, z1 in s.boundary_ranges()[0]:
-                            s.pair_range(*args, z0, z1)
+                            s.multi_range(k, *args, z0, z1)
                     _copy_halos(states, states[0].cur ^ 1)  # "in flight" while the interiors are computed
                     for s in states:
                         b0, b1 = s.boundary_ranges()[1]
-                        s.pair_range(*args, b0, b1)
+                        s.multi_range(k, *args, b0, b1)
                         s.flip()
-                    it += 2
                     continue
                 for s in states:
-                    if iters - it >= 2:
-                        s.pair(sigma, tau, lt, np.float32(1.0), 0, 1)
+                    if k >= 2:
+                        s.multi(k, *args)
                     else:
-                        s.single(sigma, tau, lt, np.float32(1.0), 0, 1)
-                it += 2 if iters - it >= 2 else 1
+                        s.single(*args)
                 _copy_halos(states, states[0].cur)
             got = torch.cat([s.result() for s in states]).cpu().numpy()
             assert np.array_equal(got, want), (iters, np.abs(got - want).max())

@@ -54,7 +54,7 @@ def _worker(rank, world, port, case):
 
 CASES = [
     dict(kind="pd", shape=(9, 7, 11), iters=6, mtv=0, nn=0, half=False),
-    dict(kind="pd", shape=(8, 6, 70), iters=5, mtv=1, nn=1, half=True),
+    dict(kind="pd", shape=(10, 6, 70), iters=5, mtv=1, nn=1, half=True),
     # slabs long enough for the overlapped schedule (edge planes, exchange in flight, interior); with 3 ranks the
     # middle slab is too short and falls back to the plain schedule while its neighbours overlap
     dict(kind="pd", shape=(19, 6, 13), iters=7, mtv=0, nn=1, half=False),
@@ -140,7 +140,7 @@ def _short_slab_worker(rank, world, port):
         from oracle import tomo_oracle as O
         from tomobar_amd.slab import SlabComm, pd_tv_slab, rof_tv_slab, slab_bounds
         comm = SlabComm(rank, world)
-        z0, z1 = slab_bounds(5, world, rank)          # 2 + 2 + 1 slices: the last slab is too short for two-plane ghosts
+        z0, z1 = slab_bounds(5, world, rank)          # 2 + 2 + 1 slices: too short for the ghost zones
         mine = torch.zeros((z1 - z0, 4, 6))
         for fn, kw in ((pd_tv_slab, dict(pair_fn=O.pd_pair_slab, step_fn=O.pd_step_slab)),
                        (rof_tv_slab, dict(step_fn=O.rof_step_slab))):
@@ -151,7 +151,7 @@ def _short_slab_worker(rank, world, port):
                 else:
                     fn(mine, comm, 0.04, 4, 0.005, False, **kw)
             except ValueError as e:   # EVERY rank raises (nobody is left waiting in a send/recv)
-                assert "fewer than 2 slices" in str(e)
+                assert "fewer than" in str(e)
             else:
                 raise AssertionError(f"rank {rank}: a too-short slab must raise on all ranks")
         dist.barrier()                                 # all ranks got here: no deadlock

@@ -79,6 +79,8 @@ SIGNATURES = {
                                  _f, _f, _f, _f, _i, _i, _i, _vp]),
     "tomo_pdtv_pair_slab_range": (_i, [_i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i,
                                        _f, _f, _f, _f, _i, _i, _i, _vp]),
+    "tomo_pdtv_multi_slab_range": (_i, [_i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i, _i,
+                                        _f, _f, _f, _f, _i, _i, _i, _vp]),
     "tomo_roftv_iter_slab": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "tomo_roftv_iter_slab_range": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "tomo_fbp_filter": (_i, [_i, _vp, _sz, _i, _f, _f, _vp]),

@@ -473,8 +473,8 @@ extern "C" int tomo_pdtv_pair_slab(int device, const float *in_dev, const float 
                                    int lo_planes, int hi_planes, float sigma, float tau, float lt, float theta,
                                    int methodTV, int nonneg, int half, void *stream)
 {
-    return tomo_pdtv_pair_slab_range(device, in_dev, u_in_dev, u_out_dev, p_in_dev, p_out_dev, dx, dy, nz_local, lo_planes,
-                                     hi_planes, 0, nz_local, sigma, tau, lt, theta, methodTV, nonneg, half, stream);
+    return tomo_pdtv_multi_slab_range(device, in_dev, u_in_dev, u_out_dev, p_in_dev, p_out_dev, dx, dy, nz_local, lo_planes,
+                                      hi_planes, 0, nz_local, 2, sigma, tau, lt, theta, methodTV, nonneg, half, stream);
 }
 
 extern "C" int tomo_pdtv_pair_slab_range(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
@@ -482,11 +482,21 @@ extern "C" int tomo_pdtv_pair_slab_range(int device, const float *in_dev, const 
                                          int lo_planes, int hi_planes, int z_begin, int z_end, float sigma, float tau,
                                          float lt, float theta, int methodTV, int nonneg, int half, void *stream)
 {
-    TOMO_REQUIRE(device >= 0 && dx > 0 && dy > 0 && nz_local >= 2, "bad slab arguments (a slab needs >= 2 slices)");
+    return tomo_pdtv_multi_slab_range(device, in_dev, u_in_dev, u_out_dev, p_in_dev, p_out_dev, dx, dy, nz_local, lo_planes,
+                                      hi_planes, z_begin, z_end, 2, sigma, tau, lt, theta, methodTV, nonneg, half, stream);
+}
+
+extern "C" int tomo_pdtv_multi_slab_range(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
+                                          const void *p_in_dev[3], void *p_out_dev[3], int dx, int dy, int nz_local,
+                                          int lo_planes, int hi_planes, int z_begin, int z_end, int k, float sigma,
+                                          float tau, float lt, float theta, int methodTV, int nonneg, int half, void *stream)
+{
+    TOMO_REQUIRE(k == 2 || k == 3, "a fused PD_TV launch carries 2 or 3 iterations (got %d)", k);
+    TOMO_REQUIRE(device >= 0 && dx > 0 && dy > 0 && nz_local >= k, "bad slab arguments (a slab needs >= %d slices)", k);
     TOMO_REQUIRE(z_begin >= 0 && z_begin <= z_end && z_end <= nz_local, "bad output plane range [%d, %d)", z_begin, z_end);
     if (z_begin == z_end) return TOMO_OK;
-    TOMO_REQUIRE((lo_planes == 0 || lo_planes == 2) && (hi_planes == 0 || hi_planes == 2),
-                 "the two-iteration slab kernel needs 0 or 2 ghost planes on either side");
+    TOMO_REQUIRE((lo_planes == 0 || lo_planes >= k) && (hi_planes == 0 || hi_planes >= k) && lo_planes <= 3 && hi_planes <= 3,
+                 "a %d-iteration slab launch needs 0 or >= %d (at most 3) ghost planes on either side", k, k);
     TOMO_ON_DEVICE(device);
     PdArgs a;
     a.in = in_dev; a.u_in = u_in_dev; a.u_out = u_out_dev;
@@ -500,8 +510,11 @@ extern "C" int tomo_pdtv_pair_slab_range(int device, const float *in_dev, const 
     a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = z_end - z_begin;
     hipStream_t st = as_stream(stream);
     tomo_prof_scope prof(PROF_PDTV, st, 1);
-    const int v = (g_variant_pdtv == 0 || g_variant_pdtv == 3) ? g_variant_pdtv : 2;  // slabs always run the per-wave-halo kernel
-    return half ? pd_multi_launch<__half>(a, 2, methodTV, nonneg, v, st) : pd_multi_launch<float>(a, 2, methodTV, nonneg, v, st);
+    // slabs always run the per-wave-halo kernels: shipped arithmetic (0), relaxed for both dual types (3), else exact;
+    // an exact three-iteration launch is variant 21
+    int v = (g_variant_pdtv == 0 || g_variant_pdtv == 3) ? g_variant_pdtv : 2;
+    if (k == 3 && v == 2) v = 21;
+    return half ? pd_multi_launch<__half>(a, k, methodTV, nonneg, v, st) : pd_multi_launch<float>(a, k, methodTV, nonneg, v, st);
 }
 
 extern "C" int tomo_roftv(int device, const float *in_dev, float *out_dev, int dx, int dy, int dz, int nd,

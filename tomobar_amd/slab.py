@@ -7,9 +7,10 @@ element-wise glue need no communication.  What does:
 
   * 3D TV couples neighbouring slices.  The slab arrays carry ghost planes which are refreshed by point-to-point
     send/recv between z-neighbours (RCCL over xGMI: one direct link per neighbour, no ring):
-      - PD_TV runs TWO iterations per kernel pass (tomo_pdtv_pair_slab), so the ghosts are two planes deep and are
-        refreshed once per pair: 8 planes up (U and P1..3 of the last two slices), 5 planes down (U of the first two
-        slices, P1..3 of the first); an odd trailing iteration uses tomo_pdtv_iter_slab on the same arrays;
+      - PD_TV runs up to THREE iterations per kernel pass (tomo_pdtv_multi_slab_range), so the ghosts are three planes
+        deep and are refreshed once per launch: 12 planes up (U and P1..3 of the last three slices), 9 planes down (U
+        of the first three slices, P1..3 of the first two); a trailing single iteration uses tomo_pdtv_iter_slab on the
+        same arrays;
       - ROF_TV: two planes of U up, one down, every iteration.
   * scalar reductions (power-method norm, PWLS weight maximum, CGLS inner products): all-reduce.
 
@@ -157,20 +158,39 @@ class SlabComm:
 
 
 # ------------------------------------------------------------------------------------------------ PD_TV on a slab
+GHOST = 3  # ghost planes below / above an interior boundary: as deep as the longest fused launch (3 iterations)
+
+
+def pd_launch_plan(iterations: int, half: bool):
+    """How tomo_pdtv cuts `iterations` into fused launches (csrc/tv_kernels.hip: step_of): 3 iterations per launch for
+    float32 duals, 2 for binary16 duals, as few single-iteration launches as possible (4 = 2 + 2).  The slab driver uses
+    the same plan, so a slab run is launch for launch the whole-volume run."""
+    kmax = 2 if half else 3
+    plan, rem = [], int(iterations)
+    while rem > 0:
+        if kmax >= 3 and rem >= 3 and rem != 4:
+            k = 3
+        else:
+            k = 2 if rem >= 2 else 1
+        plan.append(k)
+        rem -= k
+    return plan
+
+
 class PdSlab:
     """Ghosted ping-pong state of a slab-sharded PD_TV run.
 
-    Arrays address ``[lo + nz_local + hi][dy][dx]`` with ``lo = 2`` below an interior boundary (else 0) and ``hi = 2``
-    above one (else 0); the first local plane is index ``lo``."""
+    Arrays address ``[lo + nz_local + hi][dy][dx]`` with ``lo = GHOST`` below an interior boundary (else 0) and
+    ``hi = GHOST`` above one (else 0); the first local plane is index ``lo``."""
 
     def __init__(self, data: torch.Tensor, has_lo: bool, has_hi: bool, half: bool, pair_fn: Callable, step_fn: Callable):
         nzl, dy, dx = data.shape
-        if (has_lo or has_hi) and nzl < 2:
-            raise ValueError("PD_TV slabs must hold at least two slices")
+        if (has_lo or has_hi) and nzl < GHOST:
+            raise ValueError(f"PD_TV slabs must hold at least {GHOST} slices")
         self.nzl, self.dy, self.dx = nzl, dy, dx
         self.has_lo, self.has_hi = bool(has_lo), bool(has_hi)
-        self.lo = 2 if has_lo else 0
-        self.hi = 2 if has_hi else 0
+        self.lo = GHOST if has_lo else 0
+        self.hi = GHOST if has_hi else 0
         planes = nzl + self.lo + self.hi
         dev = data.device
         pd = torch.float16 if half else torch.float32
@@ -193,16 +213,23 @@ class PdSlab:
     def result(self) -> torch.Tensor:
         return self.local(self.inp if self.first else self.U[self.cur])
 
-    def pair(self, sigma, tau, lt, theta, methodTV, nonneg):
-        self.pair_range(sigma, tau, lt, theta, methodTV, nonneg, 0, self.nzl)
+    def multi(self, k, sigma, tau, lt, theta, methodTV, nonneg):
+        """k (2 or 3) iterations in one launch for every local plane."""
+        self.multi_range(k, sigma, tau, lt, theta, methodTV, nonneg, 0, self.nzl)
         self.flip()
 
-    def pair_range(self, sigma, tau, lt, theta, methodTV, nonneg, z_begin, z_end):
-        """Two iterations for the local output planes [z_begin, z_end) only (buffer set cur -> cur ^ 1, no flip)."""
+    def pair(self, sigma, tau, lt, theta, methodTV, nonneg):
+        self.multi(2, sigma, tau, lt, theta, methodTV, nonneg)
+
+    def multi_range(self, k, sigma, tau, lt, theta, methodTV, nonneg, z_begin, z_end):
+        """k iterations for the local output planes [z_begin, z_end) only (buffer set cur -> cur ^ 1, no flip)."""
         i, o = self.cur, self.cur ^ 1
         if z_end > z_begin:
             self.pair_fn(self.inp, self._u_in(), self.U[o], self.P[i], self.P[o], self.dx, self.dy, self.nzl, self.lo,
-                         self.hi, sigma, tau, lt, theta, methodTV, nonneg, self.half, (z_begin, z_end))
+                         self.hi, sigma, tau, lt, theta, methodTV, nonneg, self.half, (z_begin, z_end), k)
+
+    def pair_range(self, sigma, tau, lt, theta, methodTV, nonneg, z_begin, z_end):
+        self.multi_range(2, sigma, tau, lt, theta, methodTV, nonneg, z_begin, z_end)
 
     def _u_in(self) -> torch.Tensor:
         return self.inp if self.first else self.U[self.cur]
@@ -212,16 +239,16 @@ class PdSlab:
         self.first = False
 
     def boundary_ranges(self):
-        """Local plane ranges whose results the neighbours wait for (two planes at an interior boundary) and the rest."""
-        b0 = 2 if self.has_lo else 0
-        b1 = self.nzl - (2 if self.has_hi else 0)
-        return ([(0, b0)] if self.has_lo else []) + ([(b1, self.nzl)] if self.has_hi else []), (b0, b1)
+        """Local plane ranges whose results the neighbours wait for (GHOST planes at an interior boundary) and the rest."""
+        b0 = min(GHOST, self.nzl) if self.has_lo else 0
+        b1 = max(self.nzl - (GHOST if self.has_hi else 0), b0)
+        return ([(0, b0)] if self.has_lo else []) + ([(b1, self.nzl)] if self.has_hi and b1 < self.nzl else []), (b0, b1)
 
     def single(self, sigma, tau, lt, theta, methodTV, nonneg):
         """One iteration on the same arrays: the single-iteration kernel sees one ghost plane either side, i.e. the
-        arrays shifted by one plane where a two-plane ghost exists."""
+        arrays shifted by GHOST - 1 planes where a ghost zone exists."""
         i, o = self.cur, self.cur ^ 1
-        s = 1 if self.has_lo else 0
+        s = GHOST - 1 if self.has_lo else 0
         n = self.nzl + (1 if self.has_lo else 0) + (1 if self.has_hi else 0)
         v = lambda t: t[s:s + n]  # noqa: E731
         self.step_fn(v(self.inp), v(self._u_in()), v(self.U[o]), [v(p) for p in self.P[i]], [v(p) for p in self.P[o]],
@@ -230,50 +257,52 @@ class PdSlab:
         self.flip()
 
     # ---- ghost planes of buffer set b.  Up = to rank+1 (its lo ghosts), down = to rank-1 (its hi ghosts).
+    #      Up: U and P1..3 of the last GHOST planes; down: U of the first GHOST planes, P1..3 of the first GHOST - 1
+    #      (the duals of the deepest upper ghost are never read).
     def send_up(self, b: int):
         if not self.has_hi:
             return []
-        l1 = self.lo + self.nzl - 1
-        out = [self.U[b][l1 - 1], self.U[b][l1]]
+        e = self.lo + self.nzl
+        out = [self.U[b][e - GHOST + g] for g in range(GHOST)]
         for c in range(3):
-            out += [self.P[b][c][l1 - 1], self.P[b][c][l1]]
+            out += [self.P[b][c][e - GHOST + g] for g in range(GHOST)]
         return out
 
     def recv_down(self, b: int):
         if not self.has_lo:
             return []
-        out = [self.U[b][0], self.U[b][1]]
+        out = [self.U[b][g] for g in range(GHOST)]
         for c in range(3):
-            out += [self.P[b][c][0], self.P[b][c][1]]
+            out += [self.P[b][c][g] for g in range(GHOST)]
         return out
 
     def send_down(self, b: int):
         if not self.has_lo:
             return []
         f = self.lo
-        return [self.U[b][f], self.U[b][f + 1]] + [self.P[b][c][f] for c in range(3)]
+        return [self.U[b][f + g] for g in range(GHOST)] + [self.P[b][c][f + g] for c in range(3) for g in range(GHOST - 1)]
 
     def recv_up(self, b: int):
         if not self.has_hi:
             return []
         h = self.lo + self.nzl
-        return [self.U[b][h], self.U[b][h + 1]] + [self.P[b][c][h] for c in range(3)]
+        return [self.U[b][h + g] for g in range(GHOST)] + [self.P[b][c][h + g] for c in range(3) for g in range(GHOST - 1)]
 
-    # ---- the one exchange before the first step: two planes of Input either side (they are the ghosts of the initial
+    # ---- the one exchange before the first step: GHOST planes of Input either side (they are the ghosts of the initial
     #      primal variable as well, U^0 = Input); the initial duals are zero everywhere
     def initial_send_down(self):
-        return [self.inp[self.lo], self.inp[self.lo + 1]] if self.has_lo else []
+        return [self.inp[self.lo + g] for g in range(GHOST)] if self.has_lo else []
 
     def initial_recv_down(self):
-        return [self.inp[0], self.inp[1]] if self.has_lo else []
+        return [self.inp[g] for g in range(GHOST)] if self.has_lo else []
 
     def initial_send_up(self):
-        l1 = self.lo + self.nzl - 1
-        return [self.inp[l1 - 1], self.inp[l1]] if self.has_hi else []
+        e = self.lo + self.nzl
+        return [self.inp[e - GHOST + g] for g in range(GHOST)] if self.has_hi else []
 
     def initial_recv_up(self):
         h = self.lo + self.nzl
-        return [self.inp[h], self.inp[h + 1]] if self.has_hi else []
+        return [self.inp[h + g] for g in range(GHOST)] if self.has_hi else []
 
 
 def _ptr3(ts):
@@ -291,16 +320,16 @@ def _hip_pd_step(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, has_lo, has_hi, sig
 
 
 def _hip_pd_pair(inp, u_in, u_out, p_in, p_out, dx, dy, nzl, lo, hi, sigma, tau, lt, theta, methodTV, nonneg, half,
-                 zr=None):
+                 zr=None, k=2):
     from . import _lib as L
     from . import ops
     z0, z1 = zr if zr is not None else (0, nzl)
     with torch.cuda.device(inp.device):
-        L.check(L.lib().tomo_pdtv_pair_slab_range(inp.device.index, ops.ptr(inp), ops.ptr(u_in), ops.ptr(u_out),
-                                                  _ptr3(p_in), _ptr3(p_out), dx, dy, nzl, int(lo), int(hi), int(z0),
-                                                  int(z1), float(sigma), float(tau), float(lt), float(theta),
-                                                  int(bool(methodTV)), int(bool(nonneg)), int(bool(half)),
-                                                  ops.stream_ptr(inp)))
+        L.check(L.lib().tomo_pdtv_multi_slab_range(inp.device.index, ops.ptr(inp), ops.ptr(u_in), ops.ptr(u_out),
+                                                   _ptr3(p_in), _ptr3(p_out), dx, dy, nzl, int(lo), int(hi), int(z0),
+                                                   int(z1), int(k), float(sigma), float(tau), float(lt), float(theta),
+                                                   int(bool(methodTV)), int(bool(nonneg)), int(bool(half)),
+                                                   ops.stream_ptr(inp)))
 
 
 def pd_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, methodTV=0, nonneg=0,
@@ -311,32 +340,30 @@ def pd_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, m
     sigma = np.float32(1.0 / (lipschitz_const * tau))
     theta = np.float32(1.0)
     lt = np.float32(tau / regularisation_parameter)
-    comm.validate_slabs(data.shape[0])
+    comm.validate_slabs(data.shape[0], GHOST)
     st = PdSlab(data, comm.has_lo, comm.has_hi, half_precision, pair_fn or _hip_pd_pair, step_fn or _hip_pd_step)
     comm.exchange(st.initial_send_down(), st.initial_recv_down(), st.initial_send_up(), st.initial_recv_up())
-    it = 0
     edge_ranges, interior = st.boundary_ranges()
     # Overlap: the planes the neighbours wait for are computed first (two thin launches), their exchange runs on RCCL's
-    # stream while the interior of the slab is computed, and the next pair starts when both are done.
+    # stream while the interior of the slab is computed, and the next launch starts when both are done.
     overlap = overlap and bool(edge_ranges) and interior[1] - interior[0] >= 4
-    while it < iterations:
-        if iterations - it >= 2:
-            if overlap and it + 2 < iterations:
-                for z0, z1 in edge_ranges:
-                    st.pair_range(sigma, tau, lt, theta, methodTV, nonneg, z0, z1)
-                b = st.cur ^ 1
-                reqs = comm.exchange_start(st.send_down(b), st.recv_down(b), st.send_up(b), st.recv_up(b))
-                st.pair_range(sigma, tau, lt, theta, methodTV, nonneg, interior[0], interior[1])
-                st.flip()
-                comm.exchange_wait(reqs)
-                it += 2
-                continue
-            st.pair(sigma, tau, lt, theta, methodTV, nonneg)
-            it += 2
+    plan = pd_launch_plan(iterations, half_precision)
+    for n, k in enumerate(plan):
+        more = n + 1 < len(plan)
+        if k >= 2 and overlap and more:
+            for z0, z1 in edge_ranges:
+                st.multi_range(k, sigma, tau, lt, theta, methodTV, nonneg, z0, z1)
+            b = st.cur ^ 1
+            reqs = comm.exchange_start(st.send_down(b), st.recv_down(b), st.send_up(b), st.recv_up(b))
+            st.multi_range(k, sigma, tau, lt, theta, methodTV, nonneg, interior[0], interior[1])
+            st.flip()
+            comm.exchange_wait(reqs)
+            continue
+        if k >= 2:
+            st.multi(k, sigma, tau, lt, theta, methodTV, nonneg)
         else:
             st.single(sigma, tau, lt, theta, methodTV, nonneg)
-            it += 1
-        if it < iterations:
+        if more:
             b = st.cur
             comm.exchange(st.send_down(b), st.recv_down(b), st.send_up(b), st.recv_up(b))
     res = st.result()  # a view of the last output buffer (the buffer lives as long as the view)
