@@ -110,11 +110,13 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
 #pragma unroll
                 for (int i = 0; i < NR; ++i) U0n[i] = 0.0f;
             }
+            if (!a.p_in_zero) {  // uniform: the first launch of a prox starts from zero duals (nothing to read)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const T *pp = P_in[c] + sz * t;
+                for (int c = 0; c < 3; ++c) {
+                    const T *pp = P_in[c] + sz * t;
 #pragma unroll
-                for (int i = 0; i < NR - 1; ++i) Pw[c][i] = ldd(pp, off[i]);
+                    for (int i = 0; i < NR - 1; ++i) Pw[c][i] = ldd(pp, off[i]);
+                }
             }
             const float *ip = a.in + sz * t;
 #pragma unroll
@@ -188,10 +190,12 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
                     if (s == K - 1) {
                         if (emit_plane && emit_lane && y < dy) {
                             *(float *)((char *)(a.u_out + sz * p) + off[i]) = uo;
+                            if (!a.p_out_skip) {  // uniform: nobody reads the duals of the last launch of a prox
 #pragma unroll
-                            for (int c = 0; c < 3; ++c)
-                                DualIO<T>::st((T *)((char *)(P_out[c] + sz * p) + (sizeof(T) == 2 ? (off[i] >> 1) : off[i])),
-                                              0, Pw[c][i]);
+                                for (int c = 0; c < 3; ++c)
+                                    DualIO<T>::st((T *)((char *)(P_out[c] + sz * p) + (sizeof(T) == 2 ? (off[i] >> 1) : off[i])),
+                                                  0, Pw[c][i]);
+                            }
                         }
                     }
                 }
@@ -252,15 +256,14 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
 }
 
 template <typename T, bool NONNEG, bool ANISO, bool FAST, int K, int RY, int WX, int WY, bool LAG = false>
-static int pd_zmarch_xk_launch(PdArgs a, hipStream_t st)
+static int pd_zmarch_xk_launch(PdArgs a, hipStream_t st, long want_per_simd = 32, int min_chunk = 24)
 {
     const int nout = a.out_end - a.out_begin;
     const int gx = ceil_div(ceil_div(a.dx, 64 - 2 * K), WX), gy = ceil_div(a.dy, WY * RY);
     const int gy_per_xcd = ceil_div(gy, 8);
     const long waves_xy = (long)gx * gy * WX * WY;
-    const long want_per_simd = 32;
     int chunks = (int)((256L * 4 * want_per_simd + waves_xy - 1) / waves_xy);
-    const int max_chunks = ceil_div(nout, 24 * K);  // K warm-up planes per chunk: keep chunks long
+    const int max_chunks = ceil_div(nout, min_chunk * K);  // K warm-up planes per chunk: keep chunks long
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
     a.zchunk = ceil_div(nout, chunks);

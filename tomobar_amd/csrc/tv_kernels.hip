@@ -100,6 +100,8 @@ struct PdArgs {
     float sigma, tau, lt, theta;
     int zchunk;       // planes per z-chunk (zmarch)
     float inv1lt;     // 1 / (1 + lt), relaxed-arithmetic kernels only
+    int p_in_zero = 0;   // pd_zmarch_xk: the input duals are all zero (first launch of a prox): do not read them
+    int p_out_skip = 0;  // pd_zmarch_xk: do not store the output duals (last launch of a prox)
 };
 
 // ------------------------------------------------------------------------------------------ PD variant 1
@@ -407,7 +409,7 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
         for (int c = 0; c < nd; ++c) { P[b][c] = cur; cur += pb + skew; }
     // U_arrays[0] = data.copy() is not materialised: iteration 0 reads the caller's buffer directly;
     // duals start at zero (regularisersCuPy.py:221-223); every U / P output buffer is fully overwritten
-    for (int c = 0; c < nd; ++c) TOMO_HIP(hipMemsetAsync(P[0][c], 0, pb, st));
+    // (the multi-iteration kernel pd_zmarch_xk takes "the duals are zero" as a flag instead of reading a zeroed array)
     // 3D volumes run several iterations per launch (K = 3 or 2, see pd_multi_launch) while that many remain, then
     // single iterations; variant 1 keeps one iteration per launch (independent implementation)
     const int v = g_variant_pdtv;
@@ -433,6 +435,12 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
         const bool last = (it + step == iters);
         a.u_out = (last && out_dev != in_dev) ? out_dev : U[ob];
         for (int c = 0; c < 3; ++c) { a.p_in[c] = P[ib][c]; a.p_out[c] = P[ob][c]; }
+        const bool xk = (step == 3);  // pd_zmarch_xk launches understand the two flags below
+        if (it == 0) {
+            if (xk) a.p_in_zero = 1;
+            else for (int c = 0; c < nd; ++c) TOMO_HIP(hipMemsetAsync(P[ib][c], 0, pb, st));
+        }
+        if (last && xk) a.p_out_skip = 1;
         a.dx = dx; a.dy = dy; a.planes = dz; a.out_begin = 0; a.out_end = dz;
         a.first_is_edge = 1; a.last_is_edge = 1;
         a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = dz;
