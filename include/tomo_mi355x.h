@@ -277,7 +277,10 @@ int tomo_fourier_inv(int device, const float *data_dev, float *out_dev, int nz, 
                      int n, int ne, int unpad_m, int out_size, const float *w_host, const float *theta_host,
                      int m, float mu, int center_size, void *stream);
 
-/* kernel-variant selector for A/B measurement: name in {"bp","fp","pdtv","roftv"}; variant 0 = default */
+/* kernel-variant selector (per calling host thread): name in {"bp","fp","pdtv","roftv"}; variant 0 = shipped default.
+ * The ones a user may care about: "pdtv" / "roftv" 2 = the builds that reproduce the reference kernels' rounding
+ * sequence bit for bit (IEEE sqrt / divide; the shipped builds use v_rsq / hoisted reciprocals for float32 duals and stay
+ * within 1e-5 of them), 3 = relaxed arithmetic for binary16 duals as well.  Everything else is A/B measurement. */
 int tomo_set_variant(const char *kernel, int variant);
 
 /* In-library kernel timing for bench.py's roofline object: while enabled, every launch group of a kernel class

@@ -20,7 +20,8 @@ int tomo_fail(int code, const char *fmt, ...)
     return code;
 }
 
-int g_variant_bp = 0, g_variant_fp = 0, g_variant_pdtv = 0, g_variant_roftv = 0;
+// test / A-B switches (tomo_set_variant), per host thread: one thread's choice never changes what another launches
+thread_local int g_variant_bp = 0, g_variant_fp = 0, g_variant_pdtv = 0, g_variant_roftv = 0;
 
 extern "C" int tomo_abi_version(void) { return TOMO_ABI_VERSION; }
 extern "C" const char *tomo_last_error(void) { return g_err; }

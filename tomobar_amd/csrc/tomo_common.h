@@ -95,7 +95,7 @@ void tomo_fourier_cache_release(int device);  // cached hipFFT plans of fourier_
 void tomo_fbp_cache_release(int device);      // cached hipFFT plans / filter tables of fbp_filter.hip
 
 // kernel-variant switches (tomo_set_variant)
-extern int g_variant_bp, g_variant_fp, g_variant_pdtv, g_variant_roftv;
+extern thread_local int g_variant_bp, g_variant_fp, g_variant_pdtv, g_variant_roftv;
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
