@@ -9,8 +9,8 @@ element-wise glue need no communication.  What does:
     send/recv between z-neighbours (RCCL over xGMI: one direct link per neighbour, no ring):
       - PD_TV runs up to THREE iterations per kernel pass (tomo_pdtv_multi_slab_range), so the ghosts are three planes
         deep and are refreshed once per launch: 12 planes up (U and P1..3 of the last three slices), 9 planes down (U
-        of the first three slices, P1..3 of the first two); a trailing single iteration uses tomo_pdtv_iter_slab on the
-        same arrays;
+        of the first three slices, P1..3 of the first two), as 4 contiguous blocks per direction; a trailing single
+        iteration uses tomo_pdtv_iter_slab on the same arrays;
       - ROF_TV: two planes of U up, one down, every iteration.
   * scalar reductions (power-method norm, PWLS weight maximum, CGLS inner products): all-reduce.
 
@@ -258,51 +258,46 @@ class PdSlab:
 
     # ---- ghost planes of buffer set b.  Up = to rank+1 (its lo ghosts), down = to rank-1 (its hi ghosts).
     #      Up: U and P1..3 of the last GHOST planes; down: U of the first GHOST planes, P1..3 of the first GHOST - 1
-    #      (the duals of the deepest upper ghost are never read).
+    #      (the duals of the deepest upper ghost are never read).  Consecutive planes are one contiguous block, so an
+    #      exchange is 4 messages per direction (U, P1, P2, P3), not one per plane.
     def send_up(self, b: int):
         if not self.has_hi:
             return []
         e = self.lo + self.nzl
-        out = [self.U[b][e - GHOST + g] for g in range(GHOST)]
-        for c in range(3):
-            out += [self.P[b][c][e - GHOST + g] for g in range(GHOST)]
-        return out
+        return [self.U[b][e - GHOST:e]] + [self.P[b][c][e - GHOST:e] for c in range(3)]
 
     def recv_down(self, b: int):
         if not self.has_lo:
             return []
-        out = [self.U[b][g] for g in range(GHOST)]
-        for c in range(3):
-            out += [self.P[b][c][g] for g in range(GHOST)]
-        return out
+        return [self.U[b][0:GHOST]] + [self.P[b][c][0:GHOST] for c in range(3)]
 
     def send_down(self, b: int):
         if not self.has_lo:
             return []
         f = self.lo
-        return [self.U[b][f + g] for g in range(GHOST)] + [self.P[b][c][f + g] for c in range(3) for g in range(GHOST - 1)]
+        return [self.U[b][f:f + GHOST]] + [self.P[b][c][f:f + GHOST - 1] for c in range(3)]
 
     def recv_up(self, b: int):
         if not self.has_hi:
             return []
         h = self.lo + self.nzl
-        return [self.U[b][h + g] for g in range(GHOST)] + [self.P[b][c][h + g] for c in range(3) for g in range(GHOST - 1)]
+        return [self.U[b][h:h + GHOST]] + [self.P[b][c][h:h + GHOST - 1] for c in range(3)]
 
     # ---- the one exchange before the first step: GHOST planes of Input either side (they are the ghosts of the initial
     #      primal variable as well, U^0 = Input); the initial duals are zero everywhere
     def initial_send_down(self):
-        return [self.inp[self.lo + g] for g in range(GHOST)] if self.has_lo else []
+        return [self.inp[self.lo:self.lo + GHOST]] if self.has_lo else []
 
     def initial_recv_down(self):
-        return [self.inp[g] for g in range(GHOST)] if self.has_lo else []
+        return [self.inp[0:GHOST]] if self.has_lo else []
 
     def initial_send_up(self):
         e = self.lo + self.nzl
-        return [self.inp[e - GHOST + g] for g in range(GHOST)] if self.has_hi else []
+        return [self.inp[e - GHOST:e]] if self.has_hi else []
 
     def initial_recv_up(self):
         h = self.lo + self.nzl
-        return [self.inp[h + g] for g in range(GHOST)] if self.has_hi else []
+        return [self.inp[h:h + GHOST]] if self.has_hi else []
 
 
 def _ptr3(ts):
@@ -417,10 +412,10 @@ class RofSlab:
 
     def send_up(self, b):
         last = self.lo + self.nzl - 1
-        return [self.U[b][last - 1], self.U[b][last]]
+        return [self.U[b][last - 1:last + 1]]   # two consecutive planes: one contiguous block
 
     def recv_down(self, b):
-        return [self.U[b][0], self.U[b][1]] if self.lo else []
+        return [self.U[b][0:2]] if self.lo else []
 
     def recv_up(self, b):
         return [self.U[b][self.lo + self.nzl]] if self.hi else []
