@@ -28,12 +28,18 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, case):
+def _worker(rank, world, port, case, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev_index = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import tomo_oracle as O
         from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
@@ -41,16 +47,16 @@ def _worker(rank, world, port, case):
         from tomobar_amd import ops
         ops.set_variant("pdtv", 2)   # exact-rounding TV kernels: the comparison with the oracle below is bit for bit
         ops.set_variant("roftv", 2)
-        dev = torch.device("cuda", 0)
+        dev = torch.device("cuda", dev_index)
         nz, n, na, os_n = case["nz"], 40, 36, case["os"]
         angles = np.linspace(0, np.pi, na, endpoint=False)
         rng = np.random.default_rng(2)
         sino = np.abs(O.shepp_logan_sino(n, nz, n, angles) / n + 0.02 * rng.standard_normal((nz, na, n))).astype(np.float32)
         P = O.Projector(nz, n, n, angles, 0.0, os_n)
         z0, z1 = slab_bounds(nz, world, rank)
-        rt = RecToolsIRCuPy(n, 0, z1 - z0, 0.0, angles, n, 0, os_n if os_n > 1 else None)
+        rt = RecToolsIRCuPy(n, 0, z1 - z0, 0.0, angles, n, dev_index, os_n if os_n > 1 else None)
         rt.slab = SlabComm(rank, world, dev)
-        assert rt.slab.staged
+        assert rt.slab.staged == (backend != "nccl")
         # ---- power method over the slabs: the dominant eigenvalue of the WHOLE operator
         rt.power_seed = 3
         L_slab = rt.powermethod({"projection_data": None})
@@ -94,3 +100,14 @@ CASES = [
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['method']}-os{c['os']}-{c['fid']}-{c['reg']['method']}")
 def test_two_rank_reconstruction_matches_whole_volume(case):
     mp.start_processes(_worker, args=(2, _free_port(), case), nprocs=2, join=True, start_method="spawn")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("case", CASES[:2], ids=lambda c: f"{c['method']}-os{c['os']}-{c['fid']}-{c['reg']['method']}")
+def test_rccl_ranks_one_gpu_each(case, world):
+    """The same reconstructions with one rank PER GPU over RCCL (backend "nccl"): runs wherever the node shows at least
+    `world` GPUs (the multi-GPU scaling node), skipped on the one-GPU test box."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs on this node, found {torch.cuda.device_count()}")
+    case = dict(case, nz=case["nz"] * 2)
+    mp.start_processes(_worker, args=(world, _free_port(), case, "nccl"), nprocs=world, join=True, start_method="spawn")
