@@ -301,6 +301,13 @@ def main():
                 "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": kernels[dom]["avg_ms"], "launches": kernels[dom]["launches"],
                 "alg_bytes_per_launch": alg_bytes[dom]}
+        if dom == "pdtv":
+            # a fused PD_TV launch performs several iterations per pass through HBM: `frac` (algorithmic bytes of all its
+            # iterations / time) can exceed 1; the real-traffic rate is the honest companion figure
+            roof["iterations_per_launch"] = args.inner * sub_its / kernels[dom]["launches"]
+        if traffic is not None:
+            roof["traffic_GBps"] = traffic / kernels[dom]["avg_ms"] / 1e6
+            roof["frac_traffic"] = roof["traffic_GBps"] / HBM_PEAK_GBS
         units = args.steps if args.strong else args.steps * world
         what = (f"{nz_total} slices of {n}^2 split over {world} z-slab(s)" if args.strong
                 else f"{nz} slices of {n}^2 per GPU; slab-iterations/s over {world} z-slab(s)")
