@@ -17,7 +17,7 @@ vol = torch.rand((NZ, N, N), device="cuda")
 out = torch.empty_like(vol)
 if what.startswith("pdtv"):
     ops.set_variant("pdtv", int(what[4:].rstrip("h")))
-    PD_TV_cupy(vol, 0.01, 6, 0, 1, 12.0, 0, what.endswith("h"), out=out)  # 3 + 3 (shipped f32) or 2 + 2 + 2
+    PD_TV_cupy(vol, 0.01, int(os.environ.get("PMC_PD_ITERS", "6")), 0, 1, 12.0, 0, what.endswith("h"), out=out)  # 3 + 3 (shipped f32) or 2 + 2 + 2; 9 = first (zero duals) + middle + last (no dual stores) launch
 elif what == "roftv":
     ROF_TV_cupy(vol, 0.01, 4, 0.001, 0, False, out=out)
 elif what.startswith("stream"):   # stream<nin><nout>[v] e.g. stream54 (dword) / stream54v (float4)
