@@ -158,6 +158,10 @@ int tomo_bp3d_admm(tomo_ctx *ctx, int subset, const float *res_dev, float *z_dev
  * tomo_dot      : sum x*y -> host (cp.inner, :272,284,292);  tomo_max: max -> host (:395)
  * tomo_pwls_weights: w = max(b,1e-6) / max(max(b,1e-6))              methodsIR_CuPy.py:392-395 */
 int tomo_momentum(const float *x_dev, const float *xold_dev, float *xt_dev, float beta, size_t count, void *stream);
+/* the same update for a context's volume [nz][n][n] that also leaves the in-plane transposed X_t in the context: the NEXT
+ * tomo_fp3d* call on xt_dev (and only that one) skips its own transpose pass.  Same value as tomo_momentum, bit for bit. */
+int tomo_momentum_transposed(tomo_ctx *ctx, const float *x_dev, const float *xold_dev, float *xt_dev, float beta,
+                             void *stream);
 int tomo_admm_dual(float *u_dev, const float *z_dev, const float *x_dev, size_t count, void *stream);
 int tomo_axpby(float a, const float *x_dev, float b, float *y_dev, size_t count, void *stream);
 int tomo_scale(float a, const float *x_dev, float *y_dev, size_t count, void *stream);

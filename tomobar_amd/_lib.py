@@ -50,6 +50,7 @@ SIGNATURES = {
     "tomo_bp3d_fista_momentum": (_i, [_vp, _i, _vp, _vp, _vp, _f, _f, _i, _vp]),
     "tomo_bp3d_admm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _f, _i, _vp]),
     "tomo_momentum": (_i, [_vp, _vp, _vp, _f, _sz, _vp]),
+    "tomo_momentum_transposed": (_i, [_vp, _vp, _vp, _vp, _f, _vp]),
     "tomo_admm_dual": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "tomo_axpby": (_i, [_f, _vp, _f, _vp, _sz, _vp]),
     "tomo_scale": (_i, [_f, _vp, _vp, _sz, _vp]),

@@ -291,6 +291,34 @@ __global__ __launch_bounds__(256) void transpose_inplane_kernel(const float *__r
     }
 }
 
+// X_t = X + beta (X - X_old) (the momentum step of methodsIR_CuPy.py:475: mul then add, no fma) written twice: as is,
+// and in-plane transposed into the forward projector's scratch copy -- the next forward projection of X_t then needs no
+// transpose pass of its own (one read of X_t saved per sub-iteration)
+__global__ __launch_bounds__(256) void momentum_transpose_kernel(const float *__restrict__ x, const float *__restrict__ xold,
+                                                                float *__restrict__ xt, float *__restrict__ xt_T, float beta, int n)
+{
+    __shared__ float t[32][33];
+    const size_t zoff = (size_t)blockIdx.z * n * n;
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ly; r < 32; r += 8) {
+        const int xx = bx + lx, yy = by + r;
+        float v = 0.0f;
+        if (xx < n && yy < n) {
+            const size_t i = zoff + (size_t)yy * n + xx;
+            const float a = x[i];
+            v = a + beta * (a - xold[i]);
+            xt[i] = v;
+        }
+        t[r][lx] = v;
+    }
+    __syncthreads();
+    for (int r = ly; r < 32; r += 8) {
+        const int yy = by + lx, xx = bx + r;
+        if (xx < n && yy < n) xt_T[zoff + (size_t)xx * n + yy] = t[lx][r];
+    }
+}
+
 template <bool LERP8, bool RESID>
 __global__ __launch_bounds__(256) void fp_march_kernel(FpArgs a)
 {
@@ -353,6 +381,18 @@ __global__ __launch_bounds__(256) void fp_march_kernel(FpArgs a)
 
 #include "fp_tiled.inl"
 
+// the context's in-plane transposed volume copy (x-stepping angles read it), grow-only
+int fp_scratch(tomo_ctx *ctx)
+{
+    const size_t need = (size_t)ctx->nz * ctx->n * ctx->n * sizeof(float);
+    if (ctx->scratch_bytes < need) {
+        if (ctx->scratch) { TOMO_HIP(hipDeviceSynchronize()); TOMO_HIP(hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+        TOMO_HIP(hipMalloc(&ctx->scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    return TOMO_OK;
+}
+
 int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const float *w, int gathered, int fidelity,
            float *out, void *stream, const float *ring = nullptr, float ring_scale = 0.0f)
 {
@@ -367,17 +407,18 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
     a.vol = vol;
     a.volT = nullptr;
     if (s.n_dirx > 0) {
-        const size_t need = (size_t)ctx->nz * ctx->n * ctx->n * sizeof(float);
-        if (ctx->scratch_bytes < need) {
-            if (ctx->scratch) { TOMO_HIP(hipDeviceSynchronize()); TOMO_HIP(hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
-            TOMO_HIP(hipMalloc(&ctx->scratch, need));
-            ctx->scratch_bytes = need;
+        int rc = fp_scratch(ctx);
+        if (rc != TOMO_OK) return rc;
+        // tomo_momentum_transposed has just written this volume's transposed copy: use it once, skip the pass
+        const bool ready = ctx->volT_valid && ctx->volT_of == vol;
+        if (!ready) {
+            dim3 tg(ceil_div(ctx->n, 32), ceil_div(ctx->n, 32), ctx->nz);
+            transpose_inplane_kernel<<<tg, 256, 0, st>>>(vol, (float *)ctx->scratch, ctx->n);
+            TOMO_LAUNCH_CHECK();
         }
-        dim3 tg(ceil_div(ctx->n, 32), ceil_div(ctx->n, 32), ctx->nz);
-        transpose_inplane_kernel<<<tg, 256, 0, st>>>(vol, (float *)ctx->scratch, ctx->n);
-        TOMO_LAUNCH_CHECK();
         a.volT = (const float *)ctx->scratch;
     }
+    ctx->volT_valid = false;  // one use only: the volume may change before the next call
     a.tab = ctx->dev_table + s.table_offset;
     a.nz = ctx->nz; a.n = ctx->n; a.nu = ctx->nu; a.na = s.size; a.na_full = ctx->na;
     a.out = out; a.b = b; a.w = w; a.fidelity = fidelity; a.gathered = gathered;
@@ -581,6 +622,21 @@ extern "C" int tomo_fp3d_residual(tomo_ctx *ctx, int subset, const float *vol_de
     TOMO_REQUIRE(fidelity != TOMO_FID_PWLS || w_full_dev != nullptr, "PWLS needs the weights");
     return fp_run(ctx, subset, vol_dev, b_full_dev, fidelity == TOMO_FID_PWLS ? w_full_dev : nullptr, gathered,
                   fidelity, res_dev, stream);
+}
+
+extern "C" int tomo_momentum_transposed(tomo_ctx *ctx, const float *x_dev, const float *xold_dev, float *xt_dev, float beta,
+                                        void *stream)
+{
+    TOMO_REQUIRE(ctx != nullptr && x_dev && xold_dev && xt_dev, "NULL argument");
+    TOMO_ON_DEVICE(ctx->device);
+    int rc = fp_scratch(ctx);
+    if (rc != TOMO_OK) return rc;
+    dim3 tg(ceil_div(ctx->n, 32), ceil_div(ctx->n, 32), ctx->nz);
+    momentum_transpose_kernel<<<tg, 256, 0, as_stream(stream)>>>(x_dev, xold_dev, xt_dev, (float *)ctx->scratch, beta, ctx->n);
+    TOMO_LAUNCH_CHECK();
+    ctx->volT_of = xt_dev;
+    ctx->volT_valid = true;
+    return TOMO_OK;
 }
 
 extern "C" int tomo_fp3d_residual_ring(tomo_ctx *ctx, int subset, const float *vol_dev, const float *b_full_dev,

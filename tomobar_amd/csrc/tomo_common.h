@@ -61,6 +61,8 @@ struct tomo_ctx {
     int *dev_fp_order = nullptr;
     void *scratch = nullptr;                  // grow-only (FP: in-plane transposed volume)
     size_t scratch_bytes = 0;
+    const float *volT_of = nullptr;           // volume whose transposed copy `scratch` holds (tomo_momentum_transposed)
+    bool volT_valid = false;                  // ... valid for exactly the next forward projection of that volume
     std::string last_fp_path, last_bp_path;   // which kernels the last FP / BP call ran (tomo_ctx_kernel_path)
 };
 

@@ -210,7 +210,7 @@ class RecToolsIRCuPy:
                 else:
                     A.grad_step(res[sub], X_t, X_grad, L_inv, nonneg, sub)
                     prox_regul(self, X_grad, r, out=X_prox)
-                    ops.momentum(X_prox, X, X_t, beta)
+                    A.momentum(X_prox, X, X_t, beta)   # also leaves X_t transposed for the next forward projection
                     X, X_prox = X_prox, X
                 if use_ring:
                     # r <- soft(r, lambda) ;  r_x = r + beta (r - r_old)

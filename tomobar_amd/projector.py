@@ -242,6 +242,13 @@ class HipTools3D:
             L.check(L.lib().tomo_ring_gh_update(ops.ptr(r), ops.ptr(r_old), ops.ptr(r_x), float(lam), float(beta),
                                                 r.numel(), ops.stream_ptr(r)))
 
+    def momentum(self, x, x_old, x_t, beta):
+        """x_t = x + beta (x - x_old), leaving the in-plane transposed x_t in the context for the next forward
+        projection of x_t (which then skips its transpose pass)."""
+        with torch.cuda.device(self._device):
+            L.check(L.lib().tomo_momentum_transposed(self._ctx, ops.ptr(x), ops.ptr(x_old), ops.ptr(x_t), float(beta),
+                                                     ops.stream_ptr(x)))
+
     def grad_step(self, res, x_t, x_out, l_inv, nonneg, os_index):
         with torch.cuda.device(self._device):
             L.check(L.lib().tomo_bp3d_fista(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(x_t), ops.ptr(x_out),
