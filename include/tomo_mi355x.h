@@ -130,6 +130,18 @@ int tomo_swls_apply(float *res_dev, const float *w_full_dev, const int *src_dev,
 int tomo_ring_gh_update(float *r_dev, float *r_old_dev, float *rx_dev, float lambda, float beta, size_t count,
                         void *stream);
 
+/* ---------------------------------------------------------------- vertical centre-of-rotation component
+ * CenterRotOffset may be [angles, 2] = (horizontal, vertical) offsets (supp/funcs.py:52-55).  The context takes the
+ * horizontal components; a vertical component moves the detector of angle a by shift[a] rows, which for parallel rays is a
+ * per-angle 2-tap resampling of the detector rows (zero outside): A_v = R(+shift) A, A_v^T = A^T R(-shift).
+ * tomo_shift_rows: out[r,a,:] = (1-w) in[r0,a,:] + w in[r0+1,a,:], r0 = floor(r + sign*shift[a]) (shift_dev: float32 [na]).
+ * tomo_sino_residual: the residual of data_fidelities.py:28-39 on an already projected subset (the fused
+ * tomo_fp3d_residual cannot resample between projector and residual; ``gathered`` as there).  Not used when no vertical component is given. */
+int tomo_shift_rows(const float *in_dev, float *out_dev, int nz, int na, int nu, const float *shift_dev, float sign,
+                    void *stream);
+int tomo_sino_residual(const float *ax_dev, const float *b_full_dev, const float *w_full_dev, const int *src_dev, int nz,
+                       int na_s, int na_full, int nu, int gathered, int fidelity, float *res_dev, void *stream);
+
 /* tomo_bp3d_fista: x_out = P+( x_t - l_inv * A_s^T res )            methodsIR_CuPy.py:463-468
  *   nonneg != 0 applies the max(.,0) projection.  x_out may alias x_t. */
 int tomo_bp3d_fista(tomo_ctx *ctx, int subset, const float *res_dev, const float *xt_dev,

@@ -97,6 +97,7 @@ class Projector:
         self.nz, self.n, self.nu = int(nz), int(n), int(nu)
         self.angles = np.ascontiguousarray(angles, dtype=np.float64)
         self.na = self.angles.size
+        self.vshift = None
         cor = np.asarray(cor, dtype=np.float64)
         if cor.ndim == 0:
             self.cor = cor.reshape(1).copy()
@@ -105,10 +106,15 @@ class Projector:
             self.cor = np.ascontiguousarray(cor)
             self.cor_stride = 1
         else:
-            if np.any(cor[:, 1] != 0):
-                raise ValueError("vertical CoR component is not supported by the oracle")
+            # [angles, 2] = (horizontal, vertical), supp/funcs.py:52-55.  The detector of angle a sits cor[a, 1] rows
+            # higher, so its row r looks at slice r + cor[a, 1]: parallel rays stay in their slice and the operator is
+            # the per-slice one composed with a per-angle linear resampling of the detector rows (shift_rows below).
+            # Formula-level restatement: ASTRA, which would pin it, is not in this image ("parity unpinned" for this
+            # component; the per-slice operators it wraps are pinned as before).
             self.cor = np.ascontiguousarray(cor)
             self.cor_stride = cor.shape[1]
+            if np.any(cor[:, 1] != 0):
+                self.vshift = np.ascontiguousarray(cor[:, 1], dtype=np.float32)
         self.flags = flags
         self.os_number = int(os_number) if os_number else 1
         self.full = self._table(None)
@@ -134,18 +140,38 @@ class Projector:
     def _sel(self, subset):
         return self.full if subset is None else self.tables[subset]
 
+    def shift_rows(self, sino, subset, sign):
+        """out[r, a, :] = (1 - w) sino[r0, a, :] + w sino[r0 + 1, a, :], r0 + w = r + sign * vshift[a]; rows outside the
+        detector read as zero.  float32 throughout, one rounding per operation."""
+        idx = np.arange(self.na) if subset is None else self.subsets[subset]
+        sh = self.vshift[idx] * np.float32(sign)
+        out = np.zeros_like(sino)
+        r = np.arange(self.nz, dtype=np.float32)
+        for a in range(sino.shape[1]):
+            f = r + sh[a]
+            fl = np.floor(f)
+            w = (f - fl).astype(np.float32)[:, None]
+            r0 = fl.astype(np.int64)
+            s0 = np.where(((r0 >= 0) & (r0 < self.nz))[:, None], sino[np.clip(r0, 0, self.nz - 1), a, :], np.float32(0))
+            s1 = np.where(((r0 + 1 >= 0) & (r0 + 1 < self.nz))[:, None], sino[np.clip(r0 + 1, 0, self.nz - 1), a, :],
+                          np.float32(0))
+            out[:, a, :] = (np.float32(1) - w) * s0 + w * s1
+        return out
+
     def fp(self, vol, subset=None):
         tab, nsel = self._sel(subset)
         vol = np.ascontiguousarray(vol, dtype=np.float32)
         assert vol.shape == (self.nz, self.n, self.n), vol.shape
         sino = np.empty((self.nz, nsel, self.nu), dtype=np.float32)
         lib().orc_fp3d(_fptr(vol), _fptr(sino), self.nz, self.n, self.nu, nsel, tab, self.flags)
-        return sino
+        return sino if self.vshift is None else self.shift_rows(sino, subset, 1.0)
 
     def bp(self, sino, subset=None):
         tab, nsel = self._sel(subset)
         sino = np.ascontiguousarray(sino, dtype=np.float32)
         assert sino.shape == (self.nz, nsel, self.nu), (sino.shape, nsel)
+        if self.vshift is not None:
+            sino = np.ascontiguousarray(self.shift_rows(sino, subset, -1.0))
         vol = np.empty((self.nz, self.n, self.n), dtype=np.float32)
         lib().orc_bp3d(_fptr(sino), _fptr(vol), self.nz, self.n, self.nu, nsel, tab, self.flags)
         return vol

@@ -228,6 +228,54 @@ __global__ __launch_bounds__(256) void ring_gh_update_kernel(float *r, float *r_
     }
 }
 
+// ---- vertical centre-of-rotation component (CenterRotOffset[:, 1], supp/funcs.py:52-55): the detector of angle a sits
+//      shift[a] rows higher, i.e. detector row r looks at slice r + shift[a].  Parallel rays stay inside their slice, so the
+//      3D operator is the per-slice operator composed with a per-angle resampling of the detector rows (2-tap linear, zero
+//      outside): forward projection = resample(+shift) after A, back projection = A^T after resample(-shift).
+__global__ __launch_bounds__(256) void shift_rows_kernel(const float *__restrict__ in, float *__restrict__ out, int nz, int na,
+                                                         int nu, const float *__restrict__ shift, float sign)
+{
+    const size_t total = (size_t)nz * na * nu;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int u = (int)(i % nu);
+        const int a = (int)((i / nu) % na);
+        const int r = (int)(i / ((size_t)nu * na));
+        const float f = (float)r + sign * shift[a];
+        const float fl = floorf(f);
+        const float w = f - fl;
+        const int r0 = (int)fl;
+        const float s0 = (r0 >= 0 && r0 < nz) ? in[((size_t)r0 * na + a) * nu + u] : 0.0f;
+        const float s1 = (r0 + 1 >= 0 && r0 + 1 < nz) ? in[((size_t)(r0 + 1) * na + a) * nu + u] : 0.0f;
+        out[i] = (1.0f - w) * s0 + w * s1;
+    }
+}
+
+// residual of data_fidelities.py:28-39 on an already forward-projected subset: res = w (.) (ax - b), 1 - b / max(ax, 1e-8)
+// (KL) or b / max(ax, 1e-8) (OSEM ratio); b / w are full sinograms addressed through the subset's angle indices
+__global__ __launch_bounds__(256) void sino_residual_kernel(const float *__restrict__ ax, const float *__restrict__ b,
+                                                            const float *__restrict__ w, const int *__restrict__ src, int nz,
+                                                            int na_s, int na_full, int nu, int fidelity, int gathered, float *__restrict__ out)
+{
+    const size_t total = (size_t)nz * na_s * nu;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int u = (int)(i % nu);
+        const int a = (int)((i / nu) % na_s);
+        const size_t z = i / ((size_t)nu * na_s);
+        const size_t fi = (z * na_full + src[a]) * nu + u;
+        float val = ax[i];
+        const float bv = b[(gathered & 1) ? i : fi];
+        if (fidelity == TOMO_FID_KL || fidelity == TOMO_FID_RATIO) {
+            const float v = val < 1e-8f ? 1e-8f : val;
+            const float q = bv / v;
+            val = (fidelity == TOMO_FID_KL) ? 1.0f - q : q;
+        } else {
+            val = val - bv;
+            if (w) val = val * w[(gathered & 2) ? i : fi];
+        }
+        out[i] = val;
+    }
+}
+
 // ---- pre/post
 __global__ void pad_edge_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int nu0, int pad)
 {
@@ -354,6 +402,31 @@ extern "C" int tomo_pwls_max(const float *b, size_t count, float *out_host, void
 extern "C" int tomo_pwls_weights_scaled(const float *b, float *w, size_t count, float wmax, void *stream)
 {
     return ew_launch<1, 1>(b, nullptr, nullptr, w, nullptr, count, stream, PwlsF{wmax});
+}
+
+extern "C" int tomo_shift_rows(const float *in_dev, float *out_dev, int nz, int na, int nu, const float *shift_dev, float sign,
+                               void *stream)
+{
+    TOMO_REQUIRE(in_dev && out_dev && shift_dev && in_dev != out_dev && nz > 0 && na >= 0 && nu > 0, "bad row-shift arguments");
+    const size_t total = (size_t)nz * na * nu;
+    if (total == 0) return TOMO_OK;
+    shift_rows_kernel<<<(unsigned)std::min<size_t>((total + 255) / 256, 8192), 256, 0, as_stream(stream)>>>(
+        in_dev, out_dev, nz, na, nu, shift_dev, sign);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
+extern "C" int tomo_sino_residual(const float *ax_dev, const float *b_full_dev, const float *w_full_dev, const int *src_dev,
+                                  int nz, int na_s, int na_full, int nu, int gathered, int fidelity, float *res_dev,
+                                  void *stream)
+{
+    TOMO_REQUIRE(ax_dev && b_full_dev && src_dev && res_dev && nz > 0 && na_s >= 0 && nu > 0, "bad residual arguments");
+    const size_t total = (size_t)nz * na_s * nu;
+    if (total == 0) return TOMO_OK;
+    sino_residual_kernel<<<(unsigned)std::min<size_t>((total + 255) / 256, 8192), 256, 0, as_stream(stream)>>>(
+        ax_dev, b_full_dev, fidelity == TOMO_FID_PWLS ? w_full_dev : nullptr, src_dev, nz, na_s, na_full, nu, fidelity, gathered, res_dev);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
 }
 
 extern "C" int tomo_ring_gh_reduce(float *res_dev, const float *w_full_dev, const int *src_dev, int nz, int na_s, int na_full,

@@ -90,7 +90,8 @@ extern "C" int tomo_ctx_create(int device, int nz, int n, int nu, int na, const 
     if (cor_stride == 2)
         for (int a = 0; a < na; ++a)
             TOMO_REQUIRE(cor_host[2 * a + 1] == 0.0,
-                         "a vertical centre-of-rotation component is not supported (angle %d)", a);
+                         "the context takes horizontal offsets only: apply the vertical component (angle %d) with "
+                         "tomo_shift_rows around the projectors, as HipTools3D does", a);
     int ndev = 0;
     int rc = tomo_device_count(&ndev);
     if (rc != TOMO_OK) return rc;

@@ -127,6 +127,9 @@ class RecToolsIRCuPy:
         if x0 is None:
             x0 = self._new_vol(1.0 if method_run == "OSEM" else 0.0)
         use_os = self.OS_number > 1
+        if self.slab is not None and getattr(self.Atools, "has_vertical_shift", False):
+            raise ValueError("a vertical CoR component couples the z-slabs (detector rows are resampled across slab "
+                             "boundaries): reconstruct unsharded, or shard with whole-volume replicas")
         w = ops.pwls_weights(d["projection_data"], self.slab) if _data_["data_fidelity"] in ["PWLS", "SWLS"] else None
         return (d, a, r, x0, w, use_os)
 

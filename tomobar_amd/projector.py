@@ -92,6 +92,7 @@ class HipTools3D:
         self.ordsub_number = int(ordsub_number)
 
         self.nz, self.n = self.detectors_y, self.recon_size
+        self._vshift = None
         self.nu = self.detectors_x + 2 * self.detectors_x_pad
         self.na = self.angles_vec.size
 
@@ -101,7 +102,11 @@ class HipTools3D:
         elif cor.ndim == 1:
             cor_arr, stride = np.ascontiguousarray(cor), 1
         elif cor.ndim == 2 and cor.shape == (self.na, 2):
-            cor_arr, stride = np.ascontiguousarray(cor), 2
+            # (horizontal, vertical) per angle, supp/funcs.py:52-55.  The context takes the horizontal components; the
+            # vertical ones become a per-angle resampling of the detector rows around the per-slice operators (below).
+            cor_arr, stride = np.ascontiguousarray(cor[:, 0]), 1
+            if np.any(cor[:, 1] != 0):
+                self._vshift = np.ascontiguousarray(cor[:, 1], dtype=np.float32)
         else:
             raise ValueError("The CoR must be a scalar, a vector [angles] or an array [angles, 2]")
 
@@ -180,17 +185,46 @@ class HipTools3D:
     def _backprojOSCuPy(self, proj_data, os_index: int):
         return self.backward(proj_data, os_index)
 
+    # ------------------------------------------------------------------ vertical CoR component
+    @property
+    def has_vertical_shift(self) -> bool:
+        return self._vshift is not None
+
+    def _shift_rows(self, sino, os_index, sign, out=None):
+        """Resample the detector rows of a subset's projections by sign * CenterRotOffset[:, 1] per angle (2-tap linear,
+        zero outside): detector row r of angle a looks at slice r + shift[a]."""
+        key = self._sub(os_index)
+        tabs = self.__dict__.setdefault("_vshift_tables", {})
+        if key not in tabs:
+            idx = np.arange(self.na) if key < 0 else self.subset_indices(key)
+            tabs[key] = torch.from_numpy(np.ascontiguousarray(self._vshift[idx])).to(self._device)
+        if out is None:
+            out = torch.empty_like(sino)
+        with torch.cuda.device(self._device):
+            L.check(L.lib().tomo_shift_rows(ops.ptr(sino), ops.ptr(out), self.nz, int(sino.shape[1]), self.nu,
+                                            ops.ptr(tabs[key]), float(sign), ops.stream_ptr(sino)))
+        return out
+
+    def _adjoint_in(self, res, os_index):
+        """What the back projector takes for ``res``: the rows resampled by -shift when there is a vertical component."""
+        return res if self._vshift is None else self._shift_rows(res, os_index, -1.0)
+
     # ------------------------------------------------------------------ operators
     def forward(self, vol, os_index=None, out=None):
         vol = self._vol_in(vol)
         if out is None:
             out = torch.empty(self.sino_shape(os_index), dtype=torch.float32, device=self._device)
+        if self._vshift is not None:
+            tmp = torch.empty_like(out)
+            with torch.cuda.device(self._device):
+                L.check(L.lib().tomo_fp3d(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(tmp), ops.stream_ptr(vol)))
+            return self._shift_rows(tmp, os_index, 1.0, out)
         with torch.cuda.device(self._device):
             L.check(L.lib().tomo_fp3d(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(out), ops.stream_ptr(vol)))
         return out
 
     def backward(self, sino, os_index=None, out=None):
-        sino = self._sino_in(sino, os_index)
+        sino = self._adjoint_in(self._sino_in(sino, os_index), os_index)
         if out is None:
             out = torch.empty(self.vol_shape(), dtype=torch.float32, device=self._device)
         with torch.cuda.device(self._device):
@@ -201,6 +235,15 @@ class HipTools3D:
     def residual(self, vol, b, w, fidelity: str, os_index, out, gathered: int = 0):
         """out = w_s*(A_s vol - b_s) (LS/PWLS) or 1 - b_s/max(A_s vol, 1e-8) (KL); ``gathered`` bit0/bit1: b / w is
         already the subset's array instead of the full sinogram."""
+        if self._vshift is not None:
+            ax = self.forward(vol, os_index)
+            src = self._src_table(os_index)
+            with torch.cuda.device(self._device):
+                L.check(L.lib().tomo_sino_residual(ops.ptr(ax), ops.ptr(b), ops.ptr(w), ops.ptr(src), self.nz,
+                                                   int(src.numel()), self.na, self.nu, int(gathered), L.FID[fidelity],
+                                                   ops.ptr(out),
+                                                   ops.stream_ptr(vol)))
+            return out
         with torch.cuda.device(self._device):
             L.check(L.lib().tomo_fp3d_residual(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(b),
                                                ops.ptr(w), int(gathered), L.FID[fidelity], ops.ptr(out),
@@ -219,6 +262,8 @@ class HipTools3D:
 
     def residual_ring(self, vol, b, r_x, accelerate, os_index, out):
         """out = (A_s vol - b_s) + accelerate * r_x[z, u]  (LS residual with the Group-Huber offsets added)."""
+        if self._vshift is not None:
+            raise ValueError("the Group-Huber ring term is not supported together with a vertical CoR component")
         with torch.cuda.device(self._device):
             L.check(L.lib().tomo_fp3d_residual_ring(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(b), ops.ptr(r_x),
                                                     float(accelerate), ops.ptr(out), ops.stream_ptr(vol)))
@@ -250,17 +295,20 @@ class HipTools3D:
                                                      ops.stream_ptr(x)))
 
     def grad_step(self, res, x_t, x_out, l_inv, nonneg, os_index):
+        res = self._adjoint_in(res, os_index)
         with torch.cuda.device(self._device):
             L.check(L.lib().tomo_bp3d_fista(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(x_t), ops.ptr(x_out),
                                             float(l_inv), int(bool(nonneg)), ops.stream_ptr(x_t)))
 
     def grad_step_momentum(self, res, x_t, x_old_then_x, l_inv, beta, nonneg, os_index):
+        res = self._adjoint_in(res, os_index)
         with torch.cuda.device(self._device):
             L.check(L.lib().tomo_bp3d_fista_momentum(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(x_t),
                                                      ops.ptr(x_old_then_x), float(l_inv), float(beta),
                                                      int(bool(nonneg)), ops.stream_ptr(x_t)))
 
     def admm_z_update(self, res, z, x, u, zu_out, tau, rho, relax_on, one_minus_alpha, alpha, nonneg, os_index):
+        res = self._adjoint_in(res, os_index)
         with torch.cuda.device(self._device):
             L.check(L.lib().tomo_bp3d_admm(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(z), ops.ptr(x),
                                            ops.ptr(u), ops.ptr(zu_out), float(tau), float(rho), int(bool(relax_on)),
