@@ -21,13 +21,18 @@ constexpr int xk_p_base(int K, int RY, int s) { return s <= 1 ? 0 : xk_p_base(K,
 constexpr int xk_in_rows(int K, int RY) { return RY + 2 * (K - 2); }
 constexpr int xk_lag_slots(int K, int RY) { return xk_p_base(K, RY, K) + K * xk_in_rows(K, RY); }
 
-template <typename T, bool NONNEG, bool ANISO, bool FAST, int K, int RY, int WX, int WY, bool LAG = false>
+template <typename T, bool NONNEG, bool ANISO, bool FAST, int K, int RY, int WX, int WY, bool LAG = false, int LREG = 0>
 __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, int gx, int gy, int gy_per_xcd)
 {
     constexpr int NR = RY + 2 * K;
     constexpr int NT = 64 * WX * WY;
     constexpr int IN_BASE = xk_p_base(K, RY, K), IN_ROWS = xk_in_rows(K, RY);
-    __shared__ float lag[LAG ? xk_lag_slots(K, RY) : 1][LAG ? NT : 1];
+    // the first LREG hand-over slots stay in registers (statically indexed): trims the LDS footprint to what lets one
+    // more workgroup share the CU
+    __shared__ float lag[LAG ? xk_lag_slots(K, RY) - LREG : 1][LAG ? NT : 1];
+    float lagreg[LREG > 0 ? LREG : 1];
+#pragma unroll
+    for (int q = 0; q < (LREG > 0 ? LREG : 1); ++q) lagreg[q] = 0.0f;
     const int tid = (int)threadIdx.x;
     int j = (int)blockIdx.x >> 3;
     const int xcd = (int)blockIdx.x & 7;
@@ -56,9 +61,25 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
     unsigned off[NR];  // byte offsets of row slots -K..RY+K-1 (clamped into the volume)
 #pragma unroll
     for (int i = 0; i < NR; ++i) off[i] = (unsigned)(min(max(y0 + i - K, 0), dy - 1) * dx + xc) * 4u;
-    auto ldf = [](const float *base, unsigned boff) { return *(const float *)((const char *)base + boff); };
-    auto ldd = [](const T *base, unsigned boff) {
-        return DualIO<T>::ld((const T *)((const char *)base + (sizeof(T) == 2 ? (boff >> 1) : boff)), 0);
+    // plane-relative buffer addressing: one descriptor per (array, plane) built with scalar instructions, the lane's
+    // 32-bit byte offset goes straight into buffer_load/store ... offen.  With flat pointers the compiler keeps every
+    // row offset as a 64-bit register pair and spends one 64-bit VALU add per load (143 per step, ~60 registers).
+    const int plane_bytes = (int)(sz * 4);
+    auto ldf = [plane_bytes](const float *base, unsigned boff) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, plane_bytes, 0x00020000);
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)boff, 0, 0));
+    };
+    auto ldd = [&](const T *base, unsigned boff) {
+        if constexpr (sizeof(T) == 4) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, plane_bytes, 0x00020000);
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)boff, 0, 0));
+        } else {
+            return DualIO<T>::ld((const T *)((const char *)base + (boff >> 1)), 0);
+        }
+    };
+    auto stf = [plane_bytes](float *base, unsigned boff, float v) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, plane_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)boff, 0, 0);
     };
     const T *P_in[3] = {(const T *)a.p_in[0], (const T *)a.p_in[1], (const T *)a.p_in[2]};
     T *P_out[3] = {(T *)a.p_out[0], (T *)a.p_out[1], (T *)a.p_out[2]};
@@ -80,7 +101,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
 
     if (LAG) {
 #pragma unroll
-        for (int q = 0; q < xk_lag_slots(K, RY); ++q) lag[q][tid] = 0.0f;
+        for (int q = 0; q < xk_lag_slots(K, RY) - LREG; ++q) lag[q][tid] = 0.0f;
     }
 
     // stage s starts K-s planes below the first output plane (warm-up planes rebuild the carries and the rings)
@@ -124,7 +145,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
             if (LAG) {  // Input(t) for the later stages: ring slot t mod K
                 const int q = t % K;
 #pragma unroll
-                for (int i = 2; i < 2 + IN_ROWS; ++i) lag[IN_BASE + q * IN_ROWS + (i - 2)][tid] = In[0][i];
+                for (int i = 2; i < 2 + IN_ROWS; ++i) lag[IN_BASE - LREG + q * IN_ROWS + (i - 2)][tid] = In[0][i];
             }
         }
 #pragma unroll
@@ -148,7 +169,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
                 if (LAG && s > 0) {
                     const int q = (t + K - s) % K;
 #pragma unroll
-                    for (int r = -(K - s - 1); r <= RY + (K - s - 1) - 1; ++r) InS[r + K] = lag[IN_BASE + q * IN_ROWS + (r + K - 2)][tid];
+                    for (int r = -(K - s - 1); r <= RY + (K - s - 1) - 1; ++r) InS[r + K] = lag[IN_BASE - LREG + q * IN_ROWS + (r + K - 2)][tid];
                 }
                 // ---------------- duals, rows -(K-s) .. RY+(K-s)-2
 #pragma unroll
@@ -189,12 +210,15 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
                     Vn[i] = uo;
                     if (s == K - 1) {
                         if (emit_plane && emit_lane && y < dy) {
-                            *(float *)((char *)(a.u_out + sz * p) + off[i]) = uo;
+                            stf(a.u_out + sz * p, off[i], uo);
                             if (!a.p_out_skip) {  // uniform: nobody reads the duals of the last launch of a prox
 #pragma unroll
-                                for (int c = 0; c < 3; ++c)
-                                    DualIO<T>::st((T *)((char *)(P_out[c] + sz * p) + (sizeof(T) == 2 ? (off[i] >> 1) : off[i])),
-                                                  0, Pw[c][i]);
+                                for (int c = 0; c < 3; ++c) {
+                                    if constexpr (sizeof(T) == 4)
+                                        stf((float *)P_out[c] + sz * p, off[i], Pw[c][i]);
+                                    else
+                                        DualIO<T>::st((T *)((char *)(P_out[c] + sz * p) + (off[i] >> 1)), 0, Pw[c][i]);
+                                }
                             }
                         }
                     }
@@ -228,8 +252,14 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
                             const int i = r + K;
                             const int slot = xk_p_base(K, RY, s + 1) + c * xk_dual_rows(K, RY, s + 1) + (i - (s + 1));
                             const float nxt = Pw[c][i];
-                            const float old = lag[slot][tid];
-                            lag[slot][tid] = nxt;
+                            float old;
+                            if (slot < LREG) {
+                                old = lagreg[slot];
+                                lagreg[slot] = nxt;
+                            } else {
+                                old = lag[slot - LREG][tid];
+                                lag[slot - LREG][tid] = nxt;
+                            }
                             Pw[c][i] = (sizeof(T) == 2) ? DualIO<T>::rt(old) : old;
                         }
                 }
@@ -255,7 +285,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
     }
 }
 
-template <typename T, bool NONNEG, bool ANISO, bool FAST, int K, int RY, int WX, int WY, bool LAG = false>
+template <typename T, bool NONNEG, bool ANISO, bool FAST, int K, int RY, int WX, int WY, bool LAG = false, int LREG = 0>
 static int pd_zmarch_xk_launch(PdArgs a, hipStream_t st, long want_per_simd = 32, int min_chunk = 24)
 {
     const int nout = a.out_end - a.out_begin;
@@ -271,6 +301,6 @@ static int pd_zmarch_xk_launch(PdArgs a, hipStream_t st, long want_per_simd = 32
     a.inv1lt = 1.0f / (1.0f + a.lt);
     const long blocks = 8L * gx * gy_per_xcd * chunks;
     if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one PD_TV launch");
-    pd_zmarch_xk_kernel<T, NONNEG, ANISO, FAST, K, RY, WX, WY, LAG><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd);
+    pd_zmarch_xk_kernel<T, NONNEG, ANISO, FAST, K, RY, WX, WY, LAG, LREG><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd);
     return TOMO_OK;
 }

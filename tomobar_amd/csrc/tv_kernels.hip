@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void pd_pervoxel_kernel(PdArgs a)
 #include "pd_zmarch_xk.inl"
 
 // Several iterations in one pass through HBM (3D).  `k` = iterations of this launch (2 or 3).
-//   variant 0 (shipped): float32 duals: relaxed arithmetic, k = 3 -> pd_zmarch_xk<K=3, 4 rows, 2x2 waves, LDS lag>,
+//   variant 0 (shipped): float32 duals: relaxed arithmetic, k = 3 -> pd_zmarch_xk<K=3, 8 rows, 2x2 waves, LDS lag>,
 //                        k = 2 -> pd_zmarch_x2<2x4 waves>;  binary16 duals: exact arithmetic, k = 2 only (one flipped
 //                        binary16 rounding is 5e-4 of a dual value: relaxed arithmetic cannot hold the 1e-5 parity bar,
 //                        and the exact K = 3 kernel is VALU-bound: 6.4 vs 4.4 ms per iteration)
@@ -172,13 +172,26 @@ static int pd_iters_per_launch(int variant, int half)
     return 2;
 }
 
+// three iterations per launch.  float32 duals: 8 rows per lane, 10 of the 90 hand-over slots in registers (80 KB of LDS
+// per workgroup = two workgroups per CU), relaxed (shipped) or exact (variant 21) arithmetic on the same tiling;
+// binary16 duals (variant 21 only): 4 rows per lane, exact arithmetic
+template <typename T, bool NN, bool AN>
+int pd_xk3_launch(const PdArgs &a, int variant, hipStream_t st)
+{
+    if constexpr (sizeof(T) == 4) {
+        if (variant == 21) return pd_zmarch_xk_launch<T, NN, AN, false, 3, 8, 2, 2, true, 10>(a, st);
+        return pd_zmarch_xk_launch<T, NN, AN, true, 3, 8, 2, 2, true, 10>(a, st);
+    } else {
+        return pd_zmarch_xk_launch<T, NN, AN, false, 3, 4, 2, 2, true>(a, st);
+    }
+}
+
 template <typename T>
 int pd_multi_launch(const PdArgs &a, int k, int methodTV, int nonneg, int variant, hipStream_t st)
 {
     constexpr bool F32 = sizeof(T) == 4;
 #define PD_XK(NN, AN)                                                                                   \
-    (k == 3 ? (variant == 21 ? pd_zmarch_xk_launch<T, NN, AN, false, 3, 4, 2, 2, true>(a, st)            \
-                             : pd_zmarch_xk_launch<T, NN, AN, F32, 3, 4, 2, 2, true>(a, st))             \
+    (k == 3 ? pd_xk3_launch<T, NN, AN>(a, variant, st)                                                   \
      : variant == 10 ? pd_tile_launch<T, NN, AN, false, 4, 1, 8>(a, st)                                  \
      : variant == 11 ? pd_tile_launch<T, NN, AN, true, 4, 1, 8>(a, st)                                   \
      : variant == 20 ? pd_zmarch_xk_launch<T, NN, AN, false, 2, 4, 2, 2>(a, st)                          \
