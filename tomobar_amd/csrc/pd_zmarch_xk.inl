@@ -16,6 +16,20 @@
 // back exactly where it is consumed.  That is what lets K = 3 run with RY = 4 rows at two waves per SIMD (46 values per
 // lane would otherwise push the kernel past 256 registers): 45 row loads / 21 dual rows per 12 output-row-iterations
 // instead of 40 / 18 per 9.
+// compile-time stage loop: `s` must be a constant inside the stage body.  With a run-time (unrolled) loop the code of
+// "s + 1 < K" for the last stage survives as a dead, not yet unrolled loop with variable indices into the register
+// arrays until after the last scalar-replacement pass, which then leaves the arrays in scratch memory.
+template <typename F, int... I>
+__device__ __forceinline__ void xk_static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void xk_static_for(F &&f)
+{
+    xk_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 constexpr int xk_dual_rows(int K, int RY, int s) { return RY + 2 * (K - s) - 1; }
 constexpr int xk_p_base(int K, int RY, int s) { return s <= 1 ? 0 : xk_p_base(K, RY, s - 1) + 3 * xk_dual_rows(K, RY, s - 1); }
 constexpr int xk_in_rows(int K, int RY) { return RY + 2 * (K - 2); }
@@ -148,8 +162,8 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
                 for (int i = 2; i < 2 + IN_ROWS; ++i) lag[IN_BASE - LREG + q * IN_ROWS + (i - 2)][tid] = In[0][i];
             }
         }
-#pragma unroll
-        for (int s = 0; s < K; ++s) {
+        xk_static_for<K>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
             const int p = t - s;                                 // plane of this stage
             const bool act = (p >= max(zc0 - (K - s), 0)) && (p < dz) && (s > 0 || act0);
             float Vn[NR];                                        // U^{n+s+1}(p), rows -(K-s-1) .. RY+(K-s-1)-1
@@ -157,7 +171,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
             for (int i = 0; i < NR; ++i) Vn[i] = 0.0f;
             if (act) {
                 const bool p_last = (p == dz - 1) && a.last_is_edge;
-                if (s > 0 && !LAG) {
+                if constexpr (s > 0 && !LAG) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
                 float InS[NR];  // Input(p) of this stage
 #pragma unroll
                 for (int i = 0; i < NR; ++i) InS[i] = In[s][i];
-                if (LAG && s > 0) {
+                if constexpr (LAG && s > 0) {
                     const int q = (t + K - s) % K;
 #pragma unroll
                     for (int r = -(K - s - 1); r <= RY + (K - s - 1) - 1; ++r) InS[r + K] = lag[IN_BASE - LREG + q * IN_ROWS + (r + K - 2)][tid];
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
                     const float u = (s == 0) ? U0c[i] : Ur[s][1][i];
                     const float uo = pd_primal_t<FAST>(u, InS[i], div, a.tau, a.lt, a.inv1lt, a.theta, NONNEG);
                     Vn[i] = uo;
-                    if (s == K - 1) {
+                    if constexpr (s == K - 1) {
                         if (emit_plane && emit_lane && y < dy) {
                             stf(a.u_out + sz * p, off[i], uo);
                             if (!a.p_out_skip) {  // uniform: nobody reads the duals of the last launch of a prox
@@ -230,7 +244,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
 #pragma unroll
                 for (int i = 0; i < NR; ++i) c3[s][i] = Pw[2][i];
             }
-            if (s + 1 < K) {
+            if constexpr (s + 1 < K) {
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     Ur[s + 1][0][i] = Ur[s + 1][1][i];
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
                     Ur[s + 1][2][i] = Vn[i];
                 }
                 // P^{n+s+1}(p) is stage s+1's input at the NEXT step (stage s+1 of this step reads the previous hand-over)
-                if (!LAG) {
+                if constexpr (!LAG) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
                         }
                 }
             }
-        }
+        });
         if (!LAG) {
 #pragma unroll
             for (int s = 1; s < K; ++s)

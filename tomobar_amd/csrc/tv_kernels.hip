@@ -18,6 +18,7 @@
 //     HBM (12 B/voxel/iteration) and are evaluated once per voxel.  Variant 1: per-voxel form.
 // All arithmetic is float32 with the rounding sequence of oracle/tomo_oracle.c (explicit fmaf, -ffp-contract=off).
 #include "tomo_common.h"
+#include <utility>
 
 namespace {
 
