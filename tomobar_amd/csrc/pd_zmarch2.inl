@@ -45,10 +45,9 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch2_kernel(PdArgs a, int 
     unsigned off[RY + 2];
 #pragma unroll
     for (int r = -1; r <= RY; ++r) off[r + 1] = (unsigned)(min(max(y0 + r, 0), dy - 1) * dx + xc) * 4u;
-    auto ldf = [](const float *base, unsigned boff) { return *(const float *)((const char *)base + boff); };
-    auto ldd = [](const T *base, unsigned boff) {
-        return DualIO<T>::ld((const T *)((const char *)base + (sizeof(T) == 2 ? (boff >> 1) : boff)), 0);
-    };
+    const PlaneIO io{(int)(sz * 4)};  // plane-relative buffer addressing, see tv_kernels.hip
+    auto ldf = [&](const float *base, unsigned boff) { return io.ldf(base, boff); };
+    auto ldd = [&](const T *base, unsigned boff) { return io.ldd(base, boff); };
 
     const T *P_in[3] = {(const T *)a.p_in[0], (const T *)a.p_in[1], (const T *)a.p_in[2]};
     T *P_out[3] = {(T *)a.p_out[0], (T *)a.p_out[1], (T *)a.p_out[2]};
@@ -124,11 +123,9 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch2_kernel(PdArgs a, int 
             }
             const float uo = pd_primal_t<FAST>(Uc[r + 1], In[r], div, a.tau, a.lt, a.inv1lt, a.theta, NONNEG);
             if (emit_plane && emit_lane && y < dy) {
-                *(float *)((char *)(a.u_out + sz * z) + off[r + 1]) = uo;
+                io.stf(a.u_out + sz * z, off[r + 1], uo);
 #pragma unroll
-                for (int c = 0; c < ND; ++c)
-                    DualIO<T>::st((T *)((char *)(P_out[c] + sz * z) + (sizeof(T) == 2 ? (off[r + 1] >> 1) : off[r + 1])), 0,
-                                  Pn[c][r + 1]);
+                for (int c = 0; c < ND; ++c) io.std_(P_out[c] + sz * z, off[r + 1], Pn[c][r + 1]);
             }
         }
         if (ND == 3) {

@@ -13,7 +13,7 @@
 // lockstep barrier as pd_zmarch2 so that the overlapping rows / lines of neighbouring waves merge in L1.
 // Arithmetic and rounding are those of two successive single iterations (bit-identical; tests/test_gpu_parity.py).
 template <typename T, bool NONNEG, bool ANISO, bool FAST, int RY, int WX, int WY>
-__global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_x2_kernel(PdArgs a, int gx, int gy, int gy_per_xcd)
+__global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(1, sizeof(T) == 4 ? 2 : 8))) void pd_zmarch_x2_kernel(PdArgs a, int gx, int gy, int gy_per_xcd)
 {
     int j = (int)blockIdx.x >> 3;
     const int xcd = (int)blockIdx.x & 7;
@@ -43,10 +43,9 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_x2_kernel(PdArgs a, in
     unsigned off[RY + 4];
 #pragma unroll
     for (int r = -2; r <= RY + 1; ++r) off[r + 2] = (unsigned)(min(max(y0 + r, 0), dy - 1) * dx + xc) * 4u;
-    auto ldf = [](const float *base, unsigned boff) { return *(const float *)((const char *)base + boff); };
-    auto ldd = [](const T *base, unsigned boff) {
-        return DualIO<T>::ld((const T *)((const char *)base + (sizeof(T) == 2 ? (boff >> 1) : boff)), 0);
-    };
+    const PlaneIO io{(int)(sz * 4)};  // plane-relative buffer addressing, see tv_kernels.hip
+    auto ldf = [&](const float *base, unsigned boff) { return io.ldf(base, boff); };
+    auto ldd = [&](const T *base, unsigned boff) { return io.ldd(base, boff); };
     const T *P_in[3] = {(const T *)a.p_in[0], (const T *)a.p_in[1], (const T *)a.p_in[2]};
     T *P_out[3] = {(T *)a.p_out[0], (T *)a.p_out[1], (T *)a.p_out[2]};
 
@@ -175,11 +174,9 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_x2_kernel(PdArgs a, in
                 const float uo = pd_primal_t<FAST>(V1[r + 1], InPrev[r], div, a.tau, a.lt, a.inv1lt, a.theta, NONNEG);
                 carryB3[r] = Pb[2][r + 1];
                 if (emit_plane && emit_lane && y < dy) {
-                    *(float *)((char *)(a.u_out + sz * s) + off[r + 2]) = uo;
+                    io.stf(a.u_out + sz * s, off[r + 2], uo);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        DualIO<T>::st((T *)((char *)(P_out[c] + sz * s) + (sizeof(T) == 2 ? (off[r + 2] >> 1) : off[r + 2])), 0,
-                                      Pb[c][r + 1]);
+                    for (int c = 0; c < 3; ++c) io.std_(P_out[c] + sz * s, off[r + 2], Pb[c][r + 1]);
                 }
             }
         }

@@ -75,26 +75,9 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
     unsigned off[NR];  // byte offsets of row slots -K..RY+K-1 (clamped into the volume)
 #pragma unroll
     for (int i = 0; i < NR; ++i) off[i] = (unsigned)(min(max(y0 + i - K, 0), dy - 1) * dx + xc) * 4u;
-    // plane-relative buffer addressing: one descriptor per (array, plane) built with scalar instructions, the lane's
-    // 32-bit byte offset goes straight into buffer_load/store ... offen.  With flat pointers the compiler keeps every
-    // row offset as a 64-bit register pair and spends one 64-bit VALU add per load (143 per step, ~60 registers).
-    const int plane_bytes = (int)(sz * 4);
-    auto ldf = [plane_bytes](const float *base, unsigned boff) {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, plane_bytes, 0x00020000);
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)boff, 0, 0));
-    };
-    auto ldd = [&](const T *base, unsigned boff) {
-        if constexpr (sizeof(T) == 4) {
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, plane_bytes, 0x00020000);
-            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)boff, 0, 0));
-        } else {
-            return DualIO<T>::ld((const T *)((const char *)base + (boff >> 1)), 0);
-        }
-    };
-    auto stf = [plane_bytes](float *base, unsigned boff, float v) {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, plane_bytes, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)boff, 0, 0);
-    };
+    const PlaneIO io{(int)(sz * 4)};  // plane-relative buffer addressing, see tv_kernels.hip
+    auto ldf = [&](const float *base, unsigned boff) { return io.ldf(base, boff); };
+    auto ldd = [&](const T *base, unsigned boff) { return io.ldd(base, boff); };
     const T *P_in[3] = {(const T *)a.p_in[0], (const T *)a.p_in[1], (const T *)a.p_in[2]};
     T *P_out[3] = {(T *)a.p_out[0], (T *)a.p_out[1], (T *)a.p_out[2]};
 
@@ -224,15 +207,10 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
                     Vn[i] = uo;
                     if constexpr (s == K - 1) {
                         if (emit_plane && emit_lane && y < dy) {
-                            stf(a.u_out + sz * p, off[i], uo);
+                            io.stf(a.u_out + sz * p, off[i], uo);
                             if (!a.p_out_skip) {  // uniform: nobody reads the duals of the last launch of a prox
 #pragma unroll
-                                for (int c = 0; c < 3; ++c) {
-                                    if constexpr (sizeof(T) == 4)
-                                        stf((float *)P_out[c] + sz * p, off[i], Pw[c][i]);
-                                    else
-                                        DualIO<T>::st((T *)((char *)(P_out[c] + sz * p) + (off[i] >> 1)), 0, Pw[c][i]);
-                                }
+                                for (int c = 0; c < 3; ++c) io.std_(P_out[c] + sz * p, off[i], Pw[c][i]);
                             }
                         }
                     }

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(64 * WX * WY) void rof_zmarch_kernel(RofArgs a, int
     unsigned off[RY + 3];  // rows -2..RY, index r+2
 #pragma unroll
     for (int r = -2; r <= RY; ++r) off[r + 2] = (unsigned)(min(max(y0 + r, 0), dy - 1) * dx + xc) * 4u;
-    auto ldf = [](const float *base, unsigned boff) { return *(const float *)((const char *)base + boff); };
+    const PlaneIO io{(int)(sz * 4)};  // plane-relative buffer addressing, see tv_kernels.hip
+    auto ldf = [&](const float *base, unsigned boff) { return io.ldf(base, boff); };
 
     float Up[RY + 3], Uc[RY + 3], Un[RY + 3], carry3[RY];
 #pragma unroll
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(64 * WX * WY) void rof_zmarch_kernel(RofArgs a, int
             const float u = Uc[r + 2];
             const float tt = fmaf(a.lambda, dv, -(u - In[r]));
             const float uo = fmaf(a.tau, tt, u);
-            if (emit_plane && emit_lane && y < dy) *(float *)((char *)(a.u_out + sz * t) + off[r + 2]) = uo;
+            if (emit_plane && emit_lane && y < dy) io.stf(a.u_out + sz * t, off[r + 2], uo);
         }
         if (ND == 3) {
 #pragma unroll

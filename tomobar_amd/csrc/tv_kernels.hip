@@ -52,6 +52,42 @@ template <> struct DualIO<__half> {
 };
 
 // dual ascent + projection onto the unit ball (isotropic) / unit cube (anisotropic)
+
+// Plane-relative buffer addressing for the z-march kernels.  A lane keeps 32-bit BYTE offsets (float arrays) of its rows
+// inside one plane; the plane's base moves with scalar instructions.  With flat pointers the compiler widens every
+// offset to a 64-bit register pair and spends one 64-bit VALU add per access (143 of ~1100 VALU instructions per step and
+// ~60 registers in the three-iteration PD_TV kernel); `buffer_load/store ... offen` takes the 32-bit lane offset as is.
+// One descriptor per (array, plane): base = plane start, num_records = plane bytes (a whole volume may exceed the 4 GiB
+// a 32-bit offset can reach).
+struct PlaneIO {
+    int bytes;  // size of one float plane in bytes
+    __device__ __forceinline__ __amdgpu_buffer_rsrc_t rs(const void *plane, int nbytes) const
+    {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)plane, 0, nbytes, 0x00020000);
+    }
+    __device__ __forceinline__ float ldf(const float *plane, unsigned boff) const
+    {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs(plane, bytes), (int)boff, 0, 0));
+    }
+    __device__ __forceinline__ void stf(float *plane, unsigned boff, float v) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs(plane, bytes), (int)boff, 0, 0);
+    }
+    // dual fields: float or binary16 (boff is always the FLOAT byte offset of the voxel)
+    __device__ __forceinline__ float ldd(const float *plane, unsigned boff) const { return ldf(plane, boff); }
+    __device__ __forceinline__ void std_(float *plane, unsigned boff, float v) const { stf(plane, boff, v); }
+    __device__ __forceinline__ float ldd(const __half *plane, unsigned boff) const
+    {
+        const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(rs(plane, bytes >> 1), (int)(boff >> 1), 0, 0);
+        return __half2float(__builtin_bit_cast(__half, h));
+    }
+    __device__ __forceinline__ void std_(__half *plane, unsigned boff, float v) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, __float2half_rn(v)), rs(plane, bytes >> 1),
+                                              (int)(boff >> 1), 0, 0);
+    }
+};
+
 template <int ND, bool ANISO>
 __device__ __forceinline__ void pd_dual(float (&p)[3], const float (&g)[3], float sigma)
 {
