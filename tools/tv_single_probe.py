@@ -23,5 +23,7 @@ for half in (False, True):
     for it, label in ((1, "single"), (2, "pair"), (3, "triple")):
         ms = t(lambda: PD_TV_cupy(vol, 0.01, it, 0, 1, 12.0, 0, half, out=out))
         print(f"PD_TV {label:6s} half={int(half)}: {ms / it:6.3f} ms/iter", flush=True)
-ms = t(lambda: ROF_TV_cupy(vol, 0.01, 12, 0.002, 0, False, out=out))
-print(f"ROF_TV: {ms / 12:6.3f} ms/iter")
+for v in [int(x) for x in os.environ.get("ROF_VARIANTS", "0").split(",")]:
+    ops.set_variant("roftv", v)
+    ms = t(lambda: ROF_TV_cupy(vol, 0.01, 12, 0.002, 0, False, out=out))
+    print(f"ROF_TV v{v}: {ms / 12:6.3f} ms/iter")
