@@ -84,6 +84,8 @@ def parse():
     p.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     p.add_argument("--cpu-slices", type=int, default=8)
+    if len(sys.argv) == 1 and "TOMO_BENCH_ARGV" in os.environ and "RANK" in os.environ:  # rank started by self_launch()
+        return p.parse_args(json.loads(os.environ["TOMO_BENCH_ARGV"]))
     return p.parse_args()
 
 
@@ -98,8 +100,11 @@ def free_port():
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)]
     env = dict(os.environ)
+    # the ranks read their arguments from the environment: torch.distributed.run's own parser rejects options of this
+    # script that are prefixes of its own (e.g. --n)
+    env["TOMO_BENCH_ARGV"] = json.dumps(sys.argv[1:])
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required for RCCL between processes on this host
     env.setdefault("OMP_NUM_THREADS", "1")
     return subprocess.call(cmd, env=env)
@@ -184,14 +189,42 @@ def main():
     device = torch.device("cuda", dev_index)
     dist = None
     backend = None
+    backend_note = None
+    halo_group = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = args.backend if args.backend != "auto" else ("gloo" if oversubscribed else "nccl")
+        # the default group is gloo (host scalars: barrier, timing, consensus); the halo exchange and the solver's
+        # reductions run on an RCCL group when one comes up on EVERY rank, else on gloo with host-staged planes
+        dist.init_process_group("gloo")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group("gloo")
+            ok, why = 1, ""
+            try:
+                halo_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300))
+                probe = torch.ones(8, device=device)
+                dist.all_reduce(probe, group=halo_group)
+                ops_ = []
+                peer_buf = torch.zeros(8, device=device)
+                if rank + 1 < world:
+                    ops_.append(dist.P2POp(dist.isend, probe, rank + 1, halo_group))
+                if rank > 0:
+                    ops_.append(dist.P2POp(dist.irecv, peer_buf, rank - 1, halo_group))
+                for r_ in (dist.batch_isend_irecv(ops_) if ops_ else []):
+                    r_.wait()
+                torch.cuda.synchronize()
+                if float(probe[0].item()) != float(world) or (rank > 0 and float(peer_buf[0].item()) != float(world)):
+                    raise RuntimeError("RCCL self-test returned wrong data")
+            except Exception as e:  # noqa: BLE001 -- any failure of the transport: fall back on every rank
+                ok, why = 0, repr(e)[:200]
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                backend, halo_group = "gloo", None
+                backend_note = "RCCL group failed its self-test on some rank, fell back to host-staged gloo" + (f": {why}" if why else "")
+                if rank == 0:
+                    print("[bench] " + backend_note, file=sys.stderr)
 
     from tomobar_amd import _lib
     from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
@@ -208,7 +241,7 @@ def main():
         z0, z1 = rank * args.nz, (rank + 1) * args.nz
     nz = z1 - z0
     angles = np.linspace(0, np.pi, na, endpoint=False)
-    slab = SlabComm(rank, world, device) if world > 1 else None
+    slab = SlabComm(rank, world, device, group=halo_group) if world > 1 else None
     rt = RecToolsIRCuPy(DetectorsDimH=n, DetectorsDimH_pad=0, DetectorsDimV=nz, CenterRotOffset=0.0, AnglesVec=angles,
                         ObjSize=n, device_projector=dev_index, OS_number=args.os)
     if slab is not None:
@@ -250,7 +283,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else None)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = {k: prof_read(lib, k) for k in ("pdtv", "roftv", "bp", "fp")}
@@ -322,7 +355,8 @@ def main():
                                    f"(BASELINE configs[2])",
                        "slices_per_gpu": nz, "n": n, "angles": na, "os_number": args.os, "inner_iterations": args.inner,
                        "slices_per_sec": args.steps * nz_total / dt, "lipschitz_const": lc, "output_finite": finite,
-                       "backend": backend, "oversubscribed": oversubscribed},
+                       "backend": backend, "oversubscribed": oversubscribed,
+                       **({"backend_note": backend_note} if backend_note else {})},
             "roofline": roof, "kernels": kernels,
         }
         if not args.no_cpu and world == 1:
