@@ -411,6 +411,9 @@ def test_tv_random_shapes(oracle, ops, seed):
     want_pd = oracle.pd_tv(x, lam, iters, mtv, nn, 8.0, half)
     got = host(PD_TV_cupy(dev(x), lam, iters, mtv, nn, 8.0, 0, half))
     assert np.array_equal(got, want_pd), ("pd", shape, iters, half, mtv, nn, np.abs(got - want_pd).max())
+    ops.set_variant("pdtv", 21)  # exact arithmetic on the SHIPPED three-iteration tiling (8 rows per lane, LDS hand-over)
+    got = host(PD_TV_cupy(dev(x), lam, iters, mtv, nn, 8.0, 0, half))
+    assert np.array_equal(got, want_pd), ("pd K=3", shape, iters, half, mtv, nn, np.abs(got - want_pd).max())
     want_rof = oracle.rof_tv(x, lam, iters, 0.004, half)
     got = host(ROF_TV_cupy(dev(x), lam, iters, 0.004, 0, half))
     assert np.array_equal(got, want_rof), ("rof", shape, iters, half, np.abs(got - want_rof).max())

@@ -161,3 +161,18 @@ def test_vec_geom_matches_reference_formula():
         np.testing.assert_allclose(v[i, 9:12], [0, 0, 1], atol=1e-15)
     assert geom_size({"GridRowCount": 5, "GridColCount": 6, "GridSliceCount": 7}) == (7, 5, 6)
     assert geom_size({"DetectorRowCount": 3, "DetectorColCount": 9, "Vectors": v}) == (3, 4, 9)
+
+
+def test_bench_ranks_take_arguments_from_environment(monkeypatch):
+    """bench.py --gpus N re-executes itself under torch.distributed.run; the ranks must not receive the script's options
+    on the launcher's command line (its parser rejects e.g. --n as an ambiguous prefix of its own options)."""
+    import json
+    import sys
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("TOMO_BENCH_ARGV", json.dumps(["--gpus", "2", "--n", "256", "--nz", "32", "--strong"]))
+    a = bench.parse()
+    assert (a.gpus, a.n, a.nz, a.strong) == (2, 256, 32, True)
+    monkeypatch.delenv("RANK")
+    assert bench.parse().gpus == 1   # a plain run ignores a stale variable
