@@ -436,6 +436,7 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
     TOMO_REQUIRE(nd == 2 || nd == 3, "2D or 3D arrays must be provided only");
     if (nd == 2) dz = 1;
     TOMO_REQUIRE(dx > 0 && dy > 0 && dz > 0 && iters >= 0, "bad PD_TV dimensions / iterations");
+    TOMO_REQUIRE((size_t)dx * (size_t)dy < ((size_t)1 << 29), "a plane of %d x %d exceeds the 2 GiB a buffer descriptor of the TV kernels addresses", dx, dy);
     TOMO_REQUIRE(in_dev && out_dev, "NULL data pointer");
     TOMO_ON_DEVICE(device);
     hipStream_t st = as_stream(stream);
@@ -511,6 +512,7 @@ extern "C" int tomo_pdtv_iter_slab(int device, const float *in_dev, const float 
                                    int methodTV, int nonneg, int half, void *stream)
 {
     TOMO_REQUIRE(device >= 0 && dx > 0 && dy > 0 && nz_local > 0, "bad slab arguments");
+    TOMO_REQUIRE((size_t)dx * (size_t)dy < ((size_t)1 << 29), "a plane of %d x %d exceeds the 2 GiB a buffer descriptor of the TV kernels addresses", dx, dy);
     TOMO_ON_DEVICE(device);
     PdArgs a;
     a.in = in_dev; a.u_in = u_in_dev; a.u_out = u_out_dev;
@@ -551,6 +553,7 @@ extern "C" int tomo_pdtv_multi_slab_range(int device, const float *in_dev, const
 {
     TOMO_REQUIRE(k == 2 || k == 3, "a fused PD_TV launch carries 2 or 3 iterations (got %d)", k);
     TOMO_REQUIRE(device >= 0 && dx > 0 && dy > 0 && nz_local >= k, "bad slab arguments (a slab needs >= %d slices)", k);
+    TOMO_REQUIRE((size_t)dx * (size_t)dy < ((size_t)1 << 29), "a plane of %d x %d exceeds the 2 GiB a buffer descriptor of the TV kernels addresses", dx, dy);
     TOMO_REQUIRE(z_begin >= 0 && z_begin <= z_end && z_end <= nz_local, "bad output plane range [%d, %d)", z_begin, z_end);
     if (z_begin == z_end) return TOMO_OK;
     TOMO_REQUIRE((lo_planes == 0 || lo_planes >= k) && (hi_planes == 0 || hi_planes >= k) && lo_planes <= 3 && hi_planes <= 3,
@@ -583,6 +586,7 @@ extern "C" int tomo_roftv(int device, const float *in_dev, float *out_dev, int d
     if (nd == 2) dz = 1;
     TOMO_REQUIRE(dx >= 2 && dy >= 2 && (nd == 2 || dz >= 2) && iters >= 0,
                  "ROF_TV needs every dimension >= 2 (reflecting boundary)");
+    TOMO_REQUIRE((size_t)dx * (size_t)dy < ((size_t)1 << 29), "a plane of %d x %d exceeds the 2 GiB a buffer descriptor of the TV kernels addresses", dx, dy);
     TOMO_REQUIRE(in_dev && out_dev, "NULL data pointer");
     TOMO_ON_DEVICE(device);
     hipStream_t st = as_stream(stream);
@@ -626,6 +630,7 @@ extern "C" int tomo_roftv_iter_slab_range(int device, const float *in_dev, const
                                           int z_end, float lambda, float tau, int half, void *stream)
 {
     TOMO_REQUIRE(device >= 0 && dx >= 2 && dy >= 2 && nz_local > 0, "bad slab arguments");
+    TOMO_REQUIRE((size_t)dx * (size_t)dy < ((size_t)1 << 29), "a plane of %d x %d exceeds the 2 GiB a buffer descriptor of the TV kernels addresses", dx, dy);
     TOMO_REQUIRE(z_begin >= 0 && z_begin <= z_end && z_end <= nz_local, "bad output plane range [%d, %d)", z_begin, z_end);
     if (z_begin == z_end) return TOMO_OK;
     TOMO_REQUIRE((lo_planes == 0 || lo_planes == 2) && (hi_planes == 0 || hi_planes == 1),
