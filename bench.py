@@ -46,7 +46,7 @@ FP32_VALU_PEAK_TFLOPS = 157.3  # same guide: vector f32 peak (the issue roof of 
 # source files whose content decides the HBM traffic of each kernel class (profiles/pmc_traffic.json is only valid
 # for the sources it was measured on)
 KERNEL_SOURCES = {
-    "pdtv": ["tomobar_amd/csrc/tv_kernels.hip", "tomobar_amd/csrc/pd_tile.inl", "tomobar_amd/csrc/pd_zmarch_xk.inl", "tomobar_amd/csrc/pd_zmarch_x2.inl", "tomobar_amd/csrc/pd_zmarch2.inl"],
+    "pdtv": ["tomobar_amd/csrc/tv_kernels.hip", "tomobar_amd/csrc/pd_zmarch_xk.inl", "tomobar_amd/csrc/pd_zmarch_x2.inl", "tomobar_amd/csrc/pd_zmarch2.inl"],
     "roftv": ["tomobar_amd/csrc/tv_kernels.hip", "tomobar_amd/csrc/rof_zmarch.inl"],
     "bp": ["tomobar_amd/csrc/proj_kernels.hip", "tomobar_amd/csrc/bp_brick.inl"],
     "fp": ["tomobar_amd/csrc/proj_kernels.hip", "tomobar_amd/csrc/fp_tiled.inl"],

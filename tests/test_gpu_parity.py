@@ -186,7 +186,7 @@ def test_fused_residual_and_gradient_steps(oracle, ops):
 
 # ------------------------------------------------------------------------------------------ TV operators
 TV_SHAPES = [(6, 9, 13), (1, 20, 17), (12, 1, 70), (10, 11, 1), (8, 8, 8), (3, 5, 131), (24, 19), (20, 70, 150)]
-PD_EXACT_VARIANTS = [2, 1, 10, 20, 21]   # bit-identical to the oracle; 0 (default), 11: relaxed arithmetic (tolerance)
+PD_EXACT_VARIANTS = [2, 1, 21]   # bit-identical to the oracle; 0 (default), 3: relaxed arithmetic (tolerance)
 
 
 @pytest.mark.parametrize("shape", TV_SHAPES)
@@ -208,7 +208,7 @@ def test_pdtv_vs_oracle(oracle, ops, shape, variant):
 
 
 @pytest.mark.parametrize("shape", [(9, 40, 70), (20, 70, 150), (5, 33, 131)])
-@pytest.mark.parametrize("variant", [0, 3, 11])
+@pytest.mark.parametrize("variant", [0, 3])
 def test_pdtv_relaxed_arithmetic_vs_oracle(oracle, ops, shape, variant):
     """The relaxed-arithmetic builds (the shipped default and the tile kernel: v_rsq / v_rcp, hoisted 1/(1+lt)) stay
     within the north-star tolerance of the oracle after 60 iterations."""

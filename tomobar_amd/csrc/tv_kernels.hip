@@ -4,16 +4,14 @@
 //   tomobar/cuda_kernels/primal_dual_for_total_variation.cu:125-261 (3D), :360-452 (2D)
 //   tomobar/cuda_kernels/rudin_osher_fatemi_total_variation.cu:66-137 (2D), :156-238 (3D)
 // How it is computed here is MI355X-first:
-//   * PD_TV default: pd_tile.inl, TWO iterations per pass through HBM.  A lane owns 4 consecutive rows of one x column
-//     and marches along z; +-y neighbours are other registers of the same lane, +-x neighbours come from DPP wave
-//     shifts (2 halo lanes either side), the z-1 duals are carried in registers, iteration n+1 -> n+2 runs one plane
-//     behind iteration n -> n+1 in the same wave.  A workgroup is a stack of 8 waves owning 32 consecutive rows; the
-//     one row a wave needs from its neighbour goes through LDS, only the tile carries a two-row halo.  Odd iteration
-//     counts / the single-step slab entry use pd_zmarch2.inl (one iteration, 8 rows per lane).
+//   * PD_TV default (float32 duals): pd_zmarch_xk.inl, THREE iterations per pass through HBM.  A lane owns 8 consecutive
+//     rows of one x column and marches along z; +-y neighbours are other registers of the same lane, +-x neighbours come
+//     from DPP wave shifts (3 halo lanes either side), the z-1 duals are carried, stage s (iteration n+s -> n+s+1) runs
+//     s planes behind stage 0 in the same wave and the hand-over state lives in private LDS slots.  Two iterations per
+//     pass (binary16 duals, remainders): pd_zmarch_x2.inl; one iteration (tails, 2D): pd_zmarch2.inl.
 //     Measured history and PMC evidence: DESIGN.md sections 4 and 6.
-//   * variant 1 ("pervoxel"): one thread per voxel, neighbours' duals recomputed from global memory; variant 2: the
-//     round-1 two-iteration kernel (pd_zmarch_x2.inl: every wave re-computes its own row halos).  Both are kept as
-//     independent implementations for A/B checks.  Variants 10-13: tile shapes / relaxed arithmetic (measurement).
+//   * variant 1 ("pervoxel"): one thread per voxel, neighbours' duals recomputed from global memory -- the independent
+//     implementation kept for A/B checks; variants 2 / 21: the exact-rounding builds of the shipped kernels.
 //   * ROF_TV: rof_zmarch.inl, divergence and update fused on the same z-march skeleton: the D fields never reach
 //     HBM (12 B/voxel/iteration) and are evaluated once per voxel.  Variant 1: per-voxel form.
 // All arithmetic is float32 with the rounding sequence of oracle/tomo_oracle.c (explicit fmaf, -ffp-contract=off).
@@ -188,7 +186,43 @@ __global__ __launch_bounds__(256) void pd_pervoxel_kernel(PdArgs a)
     for (int c = 0; c < ND; ++c) DualIO<T>::st((T *)a.p_out[c], idx, p[c]);
 }
 
-#include "pd_tile.inl"
+// FAST = false: arithmetic and rounding of two successive single iterations (bit-identical to the oracle).
+// FAST = true : 1/(1+lt) hoisted to the host, v_rsq_f32 / v_rcp_f32 instead of IEEE sqrt + divide (<= 1e-6 relative).
+template <bool ANISO, bool FAST, int ND = 3>
+__device__ __forceinline__ void pd_dual_t(float (&p)[3], const float (&g)[3], float sigma)
+{
+    if (!FAST) {
+        pd_dual<ND, ANISO>(p, g, sigma);
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < ND; ++c) p[c] = fmaf(sigma, g[c], p[c]);
+    if (!ANISO) {
+        float nrm = p[0] * p[0];
+#pragma unroll
+        for (int c = 1; c < ND; ++c) nrm = fmaf(p[c], p[c], nrm);
+        const float r = nrm > 1.0f ? __builtin_amdgcn_rsqf(nrm) : 1.0f;
+#pragma unroll
+        for (int c = 0; c < ND; ++c) p[c] *= r;
+    } else {
+#pragma unroll
+        for (int c = 0; c < ND; ++c)
+            p[c] = fabsf(p[c]) > 1.0f ? copysignf(1.0f, p[c]) : p[c];  // p / |p| is exactly +-1 in IEEE arithmetic too
+    }
+}
+
+template <bool FAST>
+__device__ __forceinline__ float pd_primal_t(float u_in, float input, float div, float tau, float lt, float inv1lt,
+                                             float theta, bool nonneg)
+{
+    if (!FAST) return pd_primal(u_in, input, div, tau, lt, theta, nonneg);
+    const float u = (nonneg && u_in < 0.0f) ? 0.0f : u_in;
+    float t = fmaf(-tau, div, u);
+    t = fmaf(lt, input, t);
+    const float nu = t * inv1lt;
+    return fmaf(theta, nu - u, nu);
+}
+
 #include "pd_zmarch2.inl"
 #include "pd_zmarch_x2.inl"
 #include "pd_zmarch_xk.inl"
@@ -200,8 +234,7 @@ __global__ __launch_bounds__(256) void pd_pervoxel_kernel(PdArgs a)
 //                        and the exact K = 3 kernel is VALU-bound: 6.4 vs 4.4 ms per iteration)
 //   variant 2: the reference's exact rounding sequence for both, k = 2 (pd_zmarch_x2, 2x2 waves; bit-identical to the oracle)
 //   variant 3: relaxed arithmetic for both, k = 2
-//   variant 20 / 21: pd_zmarch_xk with exact arithmetic, K = 2 / K = 3 (bit-identical to the oracle)
-//   variant 10 / 11: workgroup-tile kernel (LDS row halos), exact / relaxed -- measured slower, see pd_tile.inl
+//   variant 21: pd_zmarch_xk K = 3 with exact arithmetic on the shipped tiling (bit-identical to the oracle)
 static int pd_iters_per_launch(int variant, int half)
 {
     if (variant == 21) return 3;
@@ -229,9 +262,6 @@ int pd_multi_launch(const PdArgs &a, int k, int methodTV, int nonneg, int varian
     constexpr bool F32 = sizeof(T) == 4;
 #define PD_XK(NN, AN)                                                                                   \
     (k == 3 ? pd_xk3_launch<T, NN, AN>(a, variant, st)                                                   \
-     : variant == 10 ? pd_tile_launch<T, NN, AN, false, 4, 1, 8>(a, st)                                  \
-     : variant == 11 ? pd_tile_launch<T, NN, AN, true, 4, 1, 8>(a, st)                                   \
-     : variant == 20 ? pd_zmarch_xk_launch<T, NN, AN, false, 2, 4, 2, 2>(a, st)                          \
      : variant == 3  ? pd_zmarch_x2_launch<T, NN, AN, true, 4, 2, 4>(a, st)                              \
      : (variant == 2 || variant == 21) ? pd_zmarch_x2_launch<T, NN, AN, false, 4, 2, 2>(a, st)           \
      : F32 ? pd_zmarch_x2_launch<T, NN, AN, true, 4, 2, 4>(a, st)                                        \

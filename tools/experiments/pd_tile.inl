@@ -1,3 +1,6 @@
+// NOT part of the build.  Round-2 experiment (PD_TV workgroup tile with LDS row halos), measured slower than the per-wave-halo
+// kernels in every shape (profiles/r2_b_pdtv_tile_vs_x2_pmc.txt).  To rebuild it: include this file in
+// tv_kernels.hip after pd_zmarch2.inl and dispatch pd_tile_launch<T, NN, AN, FAST, 4, 1, 8> from pd_multi_launch.
 // PD_TV, TWO Chambolle-Pock iterations per pass through HBM, workgroup TILE with the row halos shared through LDS
 // (3D only; default).  Included inside the anonymous namespace of tv_kernels.hip (uses PdArgs, DualIO, pd_dual, pd_primal).
 //
@@ -15,43 +18,6 @@
 // wave's 60 output columns, neighbours by DPP wave shifts.
 // Garbage computed in the tile's outermost cells (clamped loads / stale LDS slots) never reaches an output cell: stage A
 // duals are valid on tile rows [0, L-2], U^{n+1} on [1, L-2], stage B duals on [1, L-3], outputs on [2, L-3].
-// FAST = false: arithmetic and rounding of two successive single iterations (bit-identical to the oracle).
-// FAST = true : 1/(1+lt) hoisted to the host, v_rsq_f32 / v_rcp_f32 instead of IEEE sqrt + divide (<= 1e-6 relative).
-template <bool ANISO, bool FAST, int ND = 3>
-__device__ __forceinline__ void pd_dual_t(float (&p)[3], const float (&g)[3], float sigma)
-{
-    if (!FAST) {
-        pd_dual<ND, ANISO>(p, g, sigma);
-        return;
-    }
-#pragma unroll
-    for (int c = 0; c < ND; ++c) p[c] = fmaf(sigma, g[c], p[c]);
-    if (!ANISO) {
-        float nrm = p[0] * p[0];
-#pragma unroll
-        for (int c = 1; c < ND; ++c) nrm = fmaf(p[c], p[c], nrm);
-        const float r = nrm > 1.0f ? __builtin_amdgcn_rsqf(nrm) : 1.0f;
-#pragma unroll
-        for (int c = 0; c < ND; ++c) p[c] *= r;
-    } else {
-#pragma unroll
-        for (int c = 0; c < ND; ++c)
-            p[c] = fabsf(p[c]) > 1.0f ? copysignf(1.0f, p[c]) : p[c];  // p / |p| is exactly +-1 in IEEE arithmetic too
-    }
-}
-
-template <bool FAST>
-__device__ __forceinline__ float pd_primal_t(float u_in, float input, float div, float tau, float lt, float inv1lt,
-                                             float theta, bool nonneg)
-{
-    if (!FAST) return pd_primal(u_in, input, div, tau, lt, theta, nonneg);
-    const float u = (nonneg && u_in < 0.0f) ? 0.0f : u_in;
-    float t = fmaf(-tau, div, u);
-    t = fmaf(lt, input, t);
-    const float nu = t * inv1lt;
-    return fmaf(theta, nu - u, nu);
-}
-
 template <typename T, bool NONNEG, bool ANISO, bool FAST, int RY, int WX, int WY>
 __global__ __launch_bounds__(64 * WX * WY, (WX * WY <= 8 ? 2 : (WX * WY <= 12 ? 3 : 4))) void pd_tile_kernel(PdArgs a, int gx, int gy, int gy_per_xcd)
 {
