@@ -163,3 +163,40 @@ def test_config5_shape_per_gpu(oracle):
     got3 = ROF_TV_cupy(v3, 0.04, 3, 0.005, 0, False)
     want2 = torch.from_numpy(oracle.rof_tv(base, 0.04, 3, 0.005, False)).cuda()
     assert torch.equal(got3, want2.view(1, n, n).expand_as(got3))
+
+
+def test_bench_geometry_end_to_end_against_oracle(oracle, shipped=False):
+    """The bench workload's own geometry (1024-wide detector, 900 angles in 12 subsets, FISTA-OS + PD_TV) on an 8-slice
+    volume, one outer iteration = 12 sub-iterations: the kernels the bench runs (whole-row forward projector, brick
+    back projector with the FISTA epilogue, three-iteration PD_TV, momentum) in the real loop, against the CPU oracle's
+    run of the same loop -- bit for bit with the exact-rounding TV builds (the conftest default for GPU tests)."""
+    from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    n, nz, na, os_n = 1024, 8, 900, 12
+    angles = np.linspace(0, np.pi, na, endpoint=False)
+    P = oracle.Projector(nz, n, n, angles, 0.0, os_n)
+    rng = np.random.default_rng(11)
+    vol = (rng.random((nz, n, n), dtype=np.float32) * 0.2 + (np.hypot(*np.indices((n, n)) - n / 2) < 0.4 * n)).astype(np.float32)
+    sino = oracle.Projector(nz, n, n, angles, 0.0, 1).fp(vol) + np.float32(0.5) * rng.standard_normal((nz, na, n)).astype(np.float32)
+    Lc = 73000.0
+    reg = {"method": "PD_TV", "regul_param": 5e-4, "iterations": 7, "methodTV": 0, "PD_LipschitzConstant": 12.0}
+    want = oracle.fista(P, sino, 1, Lc, True, reg)
+    rt = RecToolsIRCuPy(n, 0, nz, 0.0, angles, n, 0, os_n)
+    got = rt.FISTA({"projection_data": sino, "data_axes_labels_order": ["detY", "angles", "detX"]},
+                   {"iterations": 1, "lipschitz_const": Lc, "nonnegativity": True, "recon_mask_radius": None},
+                   {"method": "PD_TV", "regul_param": 5e-4, "iterations": 7})
+    assert "whole-row" in rt.Atools.kernel_path("fp"), rt.Atools.kernel_path("fp")
+    assert "brick" in rt.Atools.kernel_path("bp"), rt.Atools.kernel_path("bp")
+    torch.cuda.synchronize()
+    g = got.cpu().numpy()
+    if shipped:
+        err = float(np.linalg.norm((g - want).astype(np.float64)) / np.linalg.norm(want.astype(np.float64)))
+        print("bench geometry, shipped TV arithmetic: rel-L2 vs oracle =", err)
+        assert err < 1e-5, err
+    else:
+        assert np.array_equal(g, want), float(np.abs(g - want).max())
+
+
+@pytest.mark.default_arithmetic
+def test_bench_geometry_end_to_end_shipped_arithmetic(oracle):
+    """The same run with the TV kernels as shipped (relaxed arithmetic): within the north-star tolerance."""
+    test_bench_geometry_end_to_end_against_oracle(oracle, shipped=True)
