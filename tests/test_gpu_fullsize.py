@@ -200,3 +200,28 @@ def test_bench_geometry_end_to_end_against_oracle(oracle, shipped=False):
 def test_bench_geometry_end_to_end_shipped_arithmetic(oracle):
     """The same run with the TV kernels as shipped (relaxed arithmetic): within the north-star tolerance."""
     test_bench_geometry_end_to_end_against_oracle(oracle, shipped=True)
+
+
+def test_config3_geometry_admm_rof_end_to_end_against_oracle(oracle):
+    """BASELINE configs[3]'s loop on its own geometry (2048-wide detector, 1500 angles, no subsets, ADMM + ROF_TV) on a
+    4-slice volume, one outer iteration: dense-angle forward projector (256-pixel tiles), brick back projector with the
+    fused ADMM z-update, ROF_TV -- bit for bit against the oracle's run of the same loop."""
+    from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    n, nz, na = 2048, 4, 1500
+    angles = np.linspace(0, np.pi, na, endpoint=False)
+    P = oracle.Projector(nz, n, n, angles, 0.0, 1)
+    rng = np.random.default_rng(12)
+    vol = (rng.random((nz, n, n), dtype=np.float32) * 0.2 + (np.hypot(*np.indices((n, n)) - n / 2) < 0.4 * n)).astype(np.float32)
+    sino = P.fp(vol) + np.float32(0.5) * rng.standard_normal((nz, na, n)).astype(np.float32)
+    Lc = 2.0e6
+    reg = {"method": "ROF_TV", "regul_param": 5e-4, "iterations": 5, "time_marching_step": 1e-3}
+    want = oracle.admm(P, sino, 1, Lc, 1.0, 1.6, True, dict(reg))
+    rt = RecToolsIRCuPy(n, 0, nz, 0.0, angles, n, 0, None)
+    got = rt.ADMM({"projection_data": sino, "data_axes_labels_order": ["detY", "angles", "detX"]},
+                  {"iterations": 1, "lipschitz_const": Lc, "nonnegativity": True, "recon_mask_radius": None,
+                   "ADMM_rho_const": 1.0, "ADMM_relax_par": 1.6},
+                  dict(reg))
+    torch.cuda.synchronize()
+    print("configs[3] kernels:", rt.Atools.kernel_path("fp"), "|", rt.Atools.kernel_path("bp"))
+    g = got.cpu().numpy()
+    assert np.array_equal(g, want), float(np.abs(g - want).max())
