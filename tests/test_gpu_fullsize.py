@@ -225,3 +225,31 @@ def test_config3_geometry_admm_rof_end_to_end_against_oracle(oracle):
     print("configs[3] kernels:", rt.Atools.kernel_path("fp"), "|", rt.Atools.kernel_path("bp"))
     g = got.cpu().numpy()
     assert np.array_equal(g, want), float(np.abs(g - want).max())
+
+
+def test_config4_geometry_fista_ring_end_to_end_against_oracle(oracle):
+    """BASELINE configs[4]'s loop on its own geometry (2560-wide detector, 1800 angles in 12 subsets, FISTA-OS + PD_TV +
+    Group-Huber ring term) on a 2-slice volume, one outer iteration: the 3-pass whole-row forward projector with the
+    ring-offset residual epilogue, the offsets' reduction / shrinkage, brick back projector, PD_TV -- bit for bit
+    against the oracle's run of the same loop (the ring term itself is formula-level)."""
+    from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    n, nz, na, os_n = 2560, 2, 1800, 12
+    angles = np.linspace(0, np.pi, na, endpoint=False)
+    P = oracle.Projector(nz, n, n, angles, 0.0, os_n)
+    rng = np.random.default_rng(13)
+    vol = (rng.random((nz, n, n), dtype=np.float32) * 0.2 + (np.hypot(*np.indices((n, n)) - n / 2) < 0.4 * n)).astype(np.float32)
+    sino = oracle.Projector(nz, n, n, angles, 0.0, 1).fp(vol) + np.float32(0.5) * rng.standard_normal((nz, na, n)).astype(np.float32)
+    sino += (rng.random((nz, 1, n), dtype=np.float32) < 0.01) * np.float32(40.0)   # stripes = rings
+    Lc = 4.0e5
+    reg = {"method": "PD_TV", "regul_param": 5e-4, "iterations": 6, "methodTV": 0, "PD_LipschitzConstant": 12.0}
+    want = oracle.fista(P, sino, 1, Lc, True, reg, ring={"lambda": 1e-4, "accelerate": 50})
+    rt = RecToolsIRCuPy(n, 0, nz, 0.0, angles, n, 0, os_n)
+    got = rt.FISTA({"projection_data": sino, "data_axes_labels_order": ["detY", "angles", "detX"],
+                    "ringGH_lambda": 1e-4, "ringGH_accelerate": 50},
+                   {"iterations": 1, "lipschitz_const": Lc, "nonnegativity": True, "recon_mask_radius": None},
+                   {"method": "PD_TV", "regul_param": 5e-4, "iterations": 6})
+    torch.cuda.synchronize()
+    print("configs[4] kernels:", rt.Atools.kernel_path("fp"), "|", rt.Atools.kernel_path("bp"))
+    g = got.cpu().numpy()
+    assert np.isfinite(want).all()
+    assert np.array_equal(g, want), float(np.abs(g - want).max())
