@@ -25,6 +25,7 @@ struct FpTiledArgs {
     int fidelity, gathered;
     int wpitch;              // LDS pitch (float4 units) per staged row, <= 256 * passes <= 1024
     int nut, ngroups, nzb;   // detector tiles, angle groups, slice quads
+    int bt;                  // whole-row form: detector pixels per tile = threads launched (a multiple of 64, <= 1024)
 };
 
 // BT = workgroup size = detector pixels per workgroup.  256: several workgroups per CU.  1024: the workgroup spans the
@@ -56,7 +57,10 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
     const int rest = q % per_zb;
     const int ut = rest % a.nut, g = rest / a.nut;
     const int z0 = zb * 4;
-    const int u0 = ut * BT;
+    // the 1024-thread form is launched with a.bt <= 1024 threads: a 2560-wide detector runs 3 tiles of 896 pixels instead
+    // of 2.5 tiles of 1024 (one sixth of the lanes idle)
+    const int bt = (BT == 1024) ? a.bt : BT;
+    const int u0 = ut * bt;
     const int tid = (int)threadIdx.x;
     const int iu = u0 + tid;
     const int n = a.n;
@@ -77,13 +81,13 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
 
     // ---- window of every march row (the sampling coordinate is monotone in the detector index, so the two ends of
     //      the detector tile bound it); two zero columns on either side (-2,-1 / n,n+1) absorb rays that miss the volume
-    for (int k = tid; k < n; k += BT) {
+    for (int k = tid; k < n; k += bt) {
         const float kw = (float)k - half_n;
         float fmin = 3.0e38f, fmax = -3.0e38f;
         for (int i = 0; i < ng; ++i) {
             const tomo_angle_t t = a.tab[ord[i]];
             const float o0 = fmaf(((float)u0 - half_u) + t.cor, t.inv, half_n);
-            const float o1 = fmaf(((float)(u0 + BT - 1) - half_u) + t.cor, t.inv, half_n);
+            const float o1 = fmaf(((float)(u0 + bt - 1) - half_u) + t.cor, t.inv, half_n);
             const float f0 = fmaf(kw, t.slope, o0), f1 = fmaf(kw, t.slope, o1);
             fmin = fminf(fmin, fminf(f0, f1));
             fmax = fmaxf(fmax, fmaxf(f0, f1));
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
             const unsigned rowoff = (unsigned)k * (unsigned)n;
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
-                const int j = tid + BT * p;
+                const int j = tid + bt * p;
                 const int x = lo + j;
                 const unsigned mk = (j < wid && x >= 0 && x < n) ? 0xffffffffu : 0u;
                 const unsigned off = rowoff + (unsigned)min(max(x, 0), n - 1);
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
         for (int r = 0; r < KC; ++r)
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
-                const int j = tid + BT * p;
+                const int j = tid + bt * p;
                 if (p == 0 || __builtin_amdgcn_readfirstlane(j - (tid & 63)) < a.wpitch)
                     if (j < a.wpitch) tile[r * a.wpitch + j] = pre[r * PASSES + p];
             }

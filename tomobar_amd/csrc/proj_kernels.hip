@@ -445,57 +445,54 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
         // the order table) are merged -- 37 angles make 5 groups of 8 instead of 3 + 3.  Chosen when the 256-pixel tiles
         // would stage >= 1.25x what whole rows need (the 12-strided angles of an ordered subset), and it fits in LDS.
         bool done[4] = {false, false, false, false};
-        {
-            size_t axis_off = s.table_offset;
-            for (int d = 0; d < 2 && g_variant_fp == 0 && a.nu >= 768; ++d) {
-                const int nc0 = s.n_class[2 * d], nc1 = s.n_class[2 * d + 1], nc = nc0 + nc1;
-                const size_t off_d = axis_off;
-                axis_off += nc;
-                if (nc == 0) continue;
-                if (s.wbound_wide[2 * d] < 0)
-                    s.wbound_wide[2 * d] = fp_window_bound(ctx->host_table.data() + s.table_offset,
-                                                           ctx->host_fp_order.data() + off_d, nc, ctx->n, ctx->nu, 1024);
-                const int wp = s.wbound_wide[2 * d];
-                const int nut_w = ceil_div(a.nu, 1024), nut = ceil_div(a.nu, 256);
-                const double cost_tiles = (double)nut * (ceil_div(nc0, FP_A) * std::max(s.wbound[2 * d], 0) +
-                                                         ceil_div(nc1, FP_A) * std::max(s.wbound[2 * d + 1], 0));
-                const double cost_rows = (double)nut_w * ceil_div(nc, FP_A) * wp;
-                const bool pays = cost_tiles >= 1.25 * cost_rows;
-                const int passes_w = ceil_div(wp, 1024);
-                // rows per chunk: 4 (or 2) double-buffered rows up to two column passes; detectors wider than 2048
-                // (3-5 passes, BASELINE configs[4] is 2560 wide) keep ONE tile (two barriers per chunk) of as many
-                // rows as fit in the 160 KiB of LDS next to the per-row window tables
-                int kc_w = 4;
-                const size_t tab_w = (size_t)a.n * 8;
-                size_t smem_w = (size_t)2 * kc_w * wp * 16 + tab_w;
-                if (passes_w <= 2) {
-                    if (smem_w > 160 * 1024) { kc_w = 2; smem_w = (size_t)2 * kc_w * wp * 16 + tab_w; }
-                } else {
-                    kc_w = passes_w == 3 ? 2 : 1;  // 3 rows (9 float4 in flight per thread) spill at 1024 threads
-                    while (kc_w > 1 && (size_t)kc_w * wp * 16 + tab_w > 160 * 1024) --kc_w;
-                    smem_w = (size_t)kc_w * wp * 16 + tab_w;
-                }
-                if (!(pays && passes_w <= 5 && smem_w <= 160 * 1024)) continue;
-                FpTiledArgs t;
-                t.src = d ? a.volT : a.vol;
-                t.tab = a.tab;
-                t.order = ctx->dev_fp_order + off_d;
-                t.n_class = nc;
-                t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
-                t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
-                t.ring = ring; t.ring_scale = ring_scale;
-                t.wpitch = wp;
-                t.nut = nut_w;
-                t.ngroups = ceil_div(nc, FP_A);
-                t.nzb = ceil_div(a.nz, 4);
-                const long blocks_w = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
-                TOMO_REQUIRE(blocks_w <= 0x7fffffffL, "problem too large for one FP launch");
+        // try_wide: whole-row form for `nc` angles starting at `off_d` of the order table (one stepping class, or the two
+        // sign classes of an axis merged); returns 1 if launched, 0 if the 256-pixel tiles are the better choice, < 0 on error
+        auto try_wide = [&](int d, size_t off_d, int nc, int &wp_cache, double cost_tiles, const char *label) -> int {
+            // tiles of equal width: 2560 pixels = 3 tiles of 896 (14 waves), not 2.5 tiles of 1024
+            const int nut_w = ceil_div(a.nu, 1024);
+            const int bt = std::min(1024, ceil_div(ceil_div(a.nu, nut_w), 64) * 64);
+            if (wp_cache < 0)
+                wp_cache = fp_window_bound(ctx->host_table.data() + s.table_offset, ctx->host_fp_order.data() + off_d, nc,
+                                           ctx->n, ctx->nu, bt);
+            const int wp = wp_cache;
+            const double cost_rows = (double)nut_w * ceil_div(nc, FP_A) * wp;
+            const bool pays = cost_tiles >= 1.25 * cost_rows;
+            const int passes_w = ceil_div(wp, bt);
+            // rows per chunk: 4 (or 2) double-buffered rows up to two column passes; detectors wider than 2048
+            // (3-5 passes, BASELINE configs[4] is 2560 wide) keep ONE tile (two barriers per chunk) of as many
+            // rows as fit in the 160 KiB of LDS next to the per-row window tables
+            int kc_w = 4;
+            const size_t tab_w = (size_t)a.n * 8;
+            size_t smem_w = (size_t)2 * kc_w * wp * 16 + tab_w;
+            if (passes_w <= 2) {
+                if (smem_w > 160 * 1024) { kc_w = 2; smem_w = (size_t)2 * kc_w * wp * 16 + tab_w; }
+            } else {
+                kc_w = passes_w == 3 ? 2 : 1;  // 3 rows (9 float4 in flight per thread) spill at 1024 threads
+                while (kc_w > 1 && (size_t)kc_w * wp * 16 + tab_w > 160 * 1024) --kc_w;
+                smem_w = (size_t)kc_w * wp * 16 + tab_w;
+            }
+            if (!(pays && passes_w <= 5 && smem_w <= 160 * 1024)) return 0;
+            FpTiledArgs t;
+            t.src = d ? a.volT : a.vol;
+            t.tab = a.tab;
+            t.order = ctx->dev_fp_order + off_d;
+            t.n_class = nc;
+            t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
+            t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
+            t.ring = ring; t.ring_scale = ring_scale;
+            t.wpitch = wp;
+            t.nut = nut_w;
+            t.bt = bt;
+            t.ngroups = ceil_div(nc, FP_A);
+            t.nzb = ceil_div(a.nz, 4);
+            const long blocks_w = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
+            if (blocks_w > 0x7fffffffL) return -1;
 #define FP_WIDE_LAUNCH(L8, RES)                                                                                        \
     do {                                                                                                               \
         auto launch = [&](auto kern) {                                                                                 \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)smem_w);                                                                    \
-            kern<<<(unsigned)blocks_w, 1024, smem_w, st>>>(t);                                                         \
+            kern<<<(unsigned)blocks_w, bt, smem_w, st>>>(t);                                                         \
         };                                                                                                             \
         if (passes_w == 1) launch(fp_tiled_kernel<L8, RES, 1, 4, true, 1024>);                                         \
         else if (passes_w == 2 && kc_w == 4) launch(fp_tiled_kernel<L8, RES, 2, 8, true, 1024>);                       \
@@ -505,14 +502,47 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
         else if (passes_w == 4) launch(fp_tiled_kernel<L8, RES, 4, 4, false, 1024>);                                   \
         else launch(fp_tiled_kernel<L8, RES, 5, 5, false, 1024>);                                                      \
     } while (0)
-                if (b) { if (l8) FP_WIDE_LAUNCH(true, true); else FP_WIDE_LAUNCH(false, true); }
-                else   { if (l8) FP_WIDE_LAUNCH(true, false); else FP_WIDE_LAUNCH(false, false); }
+            if (b) { if (l8) FP_WIDE_LAUNCH(true, true); else FP_WIDE_LAUNCH(false, true); }
+            else   { if (l8) FP_WIDE_LAUNCH(true, false); else FP_WIDE_LAUNCH(false, false); }
 #undef FP_WIDE_LAUNCH
-                TOMO_LAUNCH_CHECK();
-                ctx->last_fp_path += (d ? "x:" : "y:");
-                ctx->last_fp_path += "whole-row(1024 threads, " + std::to_string(passes_w) + " passes, " +
-                                     std::to_string(kc_w) + " rows/chunk) ";
-                done[2 * d] = done[2 * d + 1] = true;
+            if (hipGetLastError() != hipSuccess) return -1;
+            ctx->last_fp_path += label;
+            ctx->last_fp_path += "whole-row(" + std::to_string(bt) + " threads, " + std::to_string(passes_w) + " passes, " +
+                                 std::to_string(kc_w) + " rows/chunk) ";
+            return 1;
+        };
+        {
+            size_t axis_off = s.table_offset;
+            const int nut = ceil_div(a.nu, 256);
+            for (int d = 0; d < 2 && g_variant_fp == 0 && a.nu >= 768; ++d) {
+                const int nc0 = s.n_class[2 * d], nc1 = s.n_class[2 * d + 1], nc = nc0 + nc1;
+                const size_t off_d = axis_off;
+                axis_off += nc;
+                if (nc == 0) continue;
+                const double ct0 = (double)nut * ceil_div(nc0, FP_A) * std::max(s.wbound[2 * d], 0);
+                const double ct1 = (double)nut * ceil_div(nc1, FP_A) * std::max(s.wbound[2 * d + 1], 0);
+                if (a.nu <= 1024) {
+                    // one 1024-pixel tile = the whole detector row: its window does not care about the sign of the
+                    // detector slope, so the two classes of an axis (adjacent in the order table) are merged --
+                    // 37 angles make 5 groups of 8 instead of 3 + 3
+                    const int rc = try_wide(d, off_d, nc, s.wbound_wide[2 * d], ct0 + ct1, d ? "x:" : "y:");
+                    if (rc < 0) return tomo_fail(TOMO_E_INVALID, "forward-projection launch failed (or the problem is too large for one launch)");
+                    if (rc > 0) done[2 * d] = done[2 * d + 1] = true;
+                } else {
+                    // several 1024-pixel tiles per row (2560-wide detectors, BASELINE configs[4]): a group that mixes the
+                    // two signs of the slope maps a tile to BOTH ends of the volume row (window = the whole row, 2564
+                    // columns for every tile); class by class a tile's window stays ~1400 columns
+                    if (nc0 > 0) {
+                        const int rc = try_wide(d, off_d, nc0, s.wbound_wide[2 * d], ct0, d ? "x+:" : "y+:");
+                        if (rc < 0) return tomo_fail(TOMO_E_INVALID, "forward-projection launch failed (or the problem is too large for one launch)");
+                        if (rc > 0) done[2 * d] = true;
+                    }
+                    if (nc1 > 0) {
+                        const int rc = try_wide(d, off_d + nc0, nc1, s.wbound_wide[2 * d + 1], ct1, d ? "x-:" : "y-:");
+                        if (rc < 0) return tomo_fail(TOMO_E_INVALID, "forward-projection launch failed (or the problem is too large for one launch)");
+                        if (rc > 0) done[2 * d + 1] = true;
+                    }
+                }
             }
         }
         size_t order_off = s.table_offset;
@@ -535,6 +565,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 const int kc = fp_m / std::max(passes, 1);
                 const size_t smem = (size_t)(fp_db ? 2 : 1) * kc * t.wpitch * 16 + (size_t)a.n * 8;
                 t.nut = ceil_div(a.nu, 256);
+                t.bt = 256;
                 t.ngroups = ceil_div(nc, FP_A);
                 t.nzb = ceil_div(a.nz, 4);
                 const long blocks = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
