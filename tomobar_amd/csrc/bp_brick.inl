@@ -28,10 +28,15 @@ __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
 
     // XCD-aware numbering: workgroup b lands on XCD b%8; give each XCD its own z-brick stream
     const int ntiles = a.ntx * a.nty;
+    // workgroup b lands on XCD b % 8: every XCD gets one CONTIGUOUS eighth of the (z-brick, tile) list -- its own z-brick
+    // stream (the sinogram rows of a z-brick stay in that XCD's L2) and the same number of workgroups whatever nzb is
+    // (with "z-brick zb -> XCD zb % 8" a 270-slice slab = 17 z-bricks gave XCD 0 three bricks and the others two)
     const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
-    const int zb = (q / ntiles) * 8 + xcd;
-    if (zb >= a.nzb) return;  // uniform for the workgroup
-    const int tq = q % ntiles;
+    const int per_xcd = (a.nzb * ntiles + 7) >> 3;
+    const int wi = xcd * per_xcd + q;
+    if (wi >= a.nzb * ntiles) return;  // uniform for the workgroup
+    const int zb = wi / ntiles;
+    const int tq = wi % ntiles;
     const int tx0 = (tq % a.ntx) * BB_TX, ty0 = (tq / a.ntx) * BB_TY;
     const int z0 = zb * (4 * BB_ZQ);
 

@@ -52,9 +52,11 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
     // XCD-aware numbering: one slice-quad stream per XCD so that its L2 keeps that quad's rows
     const int per_zb = a.nut * a.ngroups;
     const int q = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
-    const int zb = (q / per_zb) * 8 + xcd;
-    if (zb >= a.nzb) return;
-    const int rest = q % per_zb;
+    const int per_xcd = (a.nzb * per_zb + 7) >> 3;  // a contiguous eighth of the (slice quad, tile, group) list per XCD
+    const int wi = xcd * per_xcd + q;
+    if (wi >= a.nzb * per_zb) return;
+    const int zb = wi / per_zb;
+    const int rest = wi % per_zb;
     const int ut = rest % a.nut, g = rest / a.nut;
     const int z0 = zb * 4;
     // the 1024-thread form is launched with a.bt <= 1024 threads: a 2560-wide detector runs 3 tiles of 896 pixels instead
@@ -252,9 +254,11 @@ __global__ __launch_bounds__(BT) void fp_tiled_sync_kernel(FpTiledArgs a, int kc
     __shared__ int xlo_s[8], wid_s[8];
     const int per_zb = a.nut * a.ngroups;
     const int q = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
-    const int zb = (q / per_zb) * 8 + xcd;
-    if (zb >= a.nzb) return;
-    const int rest = q % per_zb;
+    const int per_xcd = (a.nzb * per_zb + 7) >> 3;  // a contiguous eighth of the (slice quad, tile, group) list per XCD
+    const int wi = xcd * per_xcd + q;
+    if (wi >= a.nzb * per_zb) return;
+    const int zb = wi / per_zb;
+    const int rest = wi % per_zb;
     const int ut = rest % a.nut, g = rest / a.nut;
     const int z0 = zb * 4, u0 = ut * BT, tid = (int)threadIdx.x, iu = u0 + tid, n = a.n;
     const int ng = min(A, a.n_class - g * A);

@@ -12,16 +12,18 @@
 // of a workgroup walk z together (one barrier per plane) so that cache lines straddling two x segments and the halo
 // rows are requested by both users at the same moment and merge in the CU's L1 instead of becoming two HBM requests.
 template <typename T, int ND, bool NONNEG, bool ANISO, bool FAST, int RY, bool LOCKSTEP, int WX, int WY>
-__global__ __launch_bounds__(64 * WX * WY) void pd_zmarch2_kernel(PdArgs a, int gx, int gy, int gy_per_xcd)
+__global__ __launch_bounds__(64 * WX * WY) void pd_zmarch2_kernel(PdArgs a, int gx, int gy, int tiles_per_xcd)
 {
     // ---- XCD-aware workgroup numbering (gx, gy count workgroups)
-    int j = (int)blockIdx.x >> 3;
+    // every XCD owns one contiguous eighth of the row-major (yb, xb) tile list: a band of rows whose halos meet in that
+    // XCD's L2, and the same number of workgroups per XCD whatever gy is (tiles_per_xcd = ceil(gx * gy / 8))
+    const int j = (int)blockIdx.x >> 3;
     const int xcd = (int)blockIdx.x & 7;
-    const int xb = j % gx;
-    j /= gx;
-    const int yb = xcd * gy_per_xcd + (j % gy_per_xcd);
-    const int chunk = j / gy_per_xcd;
-    if (yb >= gy) return;
+    const int tq = xcd * tiles_per_xcd + (j % tiles_per_xcd);
+    const int chunk = j / tiles_per_xcd;
+    if (tq >= gx * gy) return;
+    const int xb = tq % gx;
+    const int yb = tq / gx;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -140,7 +142,7 @@ static int pd_zmarch2_launch(PdArgs a, hipStream_t st)
 {
     const int nout = a.out_end - a.out_begin;
     const int gx = ceil_div(ceil_div(a.dx, 62), WX), gy = ceil_div(a.dy, WY * RY);
-    const int gy_per_xcd = ceil_div(gy, 8);
+    const int tiles_per_xcd = ceil_div(gx * gy, 8);
     // z-chunks: enough waves to fill the chip (~8 per SIMD), each long enough to amortise its warm-up plane
     int chunks = 1;
     if (ND == 3) {
@@ -156,8 +158,8 @@ static int pd_zmarch2_launch(PdArgs a, hipStream_t st)
     a.zchunk = ceil_div(nout, chunks);
     chunks = ceil_div(nout, a.zchunk);
     a.inv1lt = 1.0f / (1.0f + a.lt);
-    const long blocks = 8L * gx * gy_per_xcd * chunks;
+    const long blocks = 8L * tiles_per_xcd * chunks;
     if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one PD_TV launch");
-    pd_zmarch2_kernel<T, ND, NONNEG, ANISO, FAST, RY, LOCKSTEP, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd);
+    pd_zmarch2_kernel<T, ND, NONNEG, ANISO, FAST, RY, LOCKSTEP, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, tiles_per_xcd);
     return TOMO_OK;
 }

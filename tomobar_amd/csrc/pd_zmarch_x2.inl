@@ -13,15 +13,17 @@
 // lockstep barrier as pd_zmarch2 so that the overlapping rows / lines of neighbouring waves merge in L1.
 // Arithmetic and rounding are those of two successive single iterations (bit-identical; tests/test_gpu_parity.py).
 template <typename T, bool NONNEG, bool ANISO, bool FAST, int RY, int WX, int WY>
-__global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(1, sizeof(T) == 4 ? 2 : 8))) void pd_zmarch_x2_kernel(PdArgs a, int gx, int gy, int gy_per_xcd)
+__global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(1, sizeof(T) == 4 ? 2 : 8))) void pd_zmarch_x2_kernel(PdArgs a, int gx, int gy, int tiles_per_xcd)
 {
-    int j = (int)blockIdx.x >> 3;
+    // every XCD owns one contiguous eighth of the row-major (yb, xb) tile list: a band of rows whose halos meet in that
+    // XCD's L2, and the same number of workgroups per XCD whatever gy is (tiles_per_xcd = ceil(gx * gy / 8))
+    const int j = (int)blockIdx.x >> 3;
     const int xcd = (int)blockIdx.x & 7;
-    const int xb = j % gx;
-    j /= gx;
-    const int yb = xcd * gy_per_xcd + (j % gy_per_xcd);
-    const int chunk = j / gy_per_xcd;
-    if (yb >= gy) return;
+    const int tq = xcd * tiles_per_xcd + (j % tiles_per_xcd);
+    const int chunk = j / tiles_per_xcd;
+    if (tq >= gx * gy) return;
+    const int xb = tq % gx;
+    const int yb = tq / gx;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -201,7 +203,7 @@ static int pd_zmarch_x2_launch(PdArgs a, hipStream_t st)
 {
     const int nout = a.out_end - a.out_begin;
     const int gx = ceil_div(ceil_div(a.dx, 60), WX), gy = ceil_div(a.dy, WY * RY);
-    const int gy_per_xcd = ceil_div(gy, 8);
+    const int tiles_per_xcd = ceil_div(gx * gy, 8);
     const long waves_xy = (long)gx * gy * WX * WY;
     const long want_per_simd = 32;
     int chunks = (int)((256L * 4 * want_per_simd + waves_xy - 1) / waves_xy);
@@ -211,8 +213,8 @@ static int pd_zmarch_x2_launch(PdArgs a, hipStream_t st)
     a.zchunk = ceil_div(nout, chunks);
     chunks = ceil_div(nout, a.zchunk);
     a.inv1lt = 1.0f / (1.0f + a.lt);
-    const long blocks = 8L * gx * gy_per_xcd * chunks;
+    const long blocks = 8L * tiles_per_xcd * chunks;
     if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one PD_TV launch");
-    pd_zmarch_x2_kernel<T, NONNEG, ANISO, FAST, RY, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd);
+    pd_zmarch_x2_kernel<T, NONNEG, ANISO, FAST, RY, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, tiles_per_xcd);
     return TOMO_OK;
 }

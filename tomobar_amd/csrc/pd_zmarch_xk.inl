@@ -36,7 +36,7 @@ constexpr int xk_in_rows(int K, int RY) { return RY + 2 * (K - 2); }
 constexpr int xk_lag_slots(int K, int RY) { return xk_p_base(K, RY, K) + K * xk_in_rows(K, RY); }
 
 template <typename T, bool NONNEG, bool ANISO, bool FAST, int K, int RY, int WX, int WY, bool LAG = false, int LREG = 0>
-__global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, int gx, int gy, int gy_per_xcd)
+__global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, int gx, int gy, int tiles_per_xcd)
 {
     constexpr int NR = RY + 2 * K;
     constexpr int NT = 64 * WX * WY;
@@ -48,13 +48,15 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
 #pragma unroll
     for (int q = 0; q < (LREG > 0 ? LREG : 1); ++q) lagreg[q] = 0.0f;
     const int tid = (int)threadIdx.x;
-    int j = (int)blockIdx.x >> 3;
+    // every XCD owns one contiguous eighth of the row-major (yb, xb) tile list: a band of rows whose halos meet in that
+    // XCD's L2, and the same number of workgroups per XCD whatever gy is (tiles_per_xcd = ceil(gx * gy / 8))
+    const int j = (int)blockIdx.x >> 3;
     const int xcd = (int)blockIdx.x & 7;
-    const int xb = j % gx;
-    j /= gx;
-    const int yb = xcd * gy_per_xcd + (j % gy_per_xcd);
-    const int chunk = j / gy_per_xcd;
-    if (yb >= gy) return;
+    const int tq = xcd * tiles_per_xcd + (j % tiles_per_xcd);
+    const int chunk = j / tiles_per_xcd;
+    if (tq >= gx * gy) return;
+    const int xb = tq % gx;
+    const int yb = tq / gx;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -282,7 +284,7 @@ static int pd_zmarch_xk_launch(PdArgs a, hipStream_t st, long want_per_simd = 32
 {
     const int nout = a.out_end - a.out_begin;
     const int gx = ceil_div(ceil_div(a.dx, 64 - 2 * K), WX), gy = ceil_div(a.dy, WY * RY);
-    const int gy_per_xcd = ceil_div(gy, 8);
+    const int tiles_per_xcd = ceil_div(gx * gy, 8);
     const long waves_xy = (long)gx * gy * WX * WY;
     int chunks = (int)((256L * 4 * want_per_simd + waves_xy - 1) / waves_xy);
     const int max_chunks = ceil_div(nout, min_chunk * K);  // K warm-up planes per chunk: keep chunks long
@@ -291,8 +293,8 @@ static int pd_zmarch_xk_launch(PdArgs a, hipStream_t st, long want_per_simd = 32
     a.zchunk = ceil_div(nout, chunks);
     chunks = ceil_div(nout, a.zchunk);
     a.inv1lt = 1.0f / (1.0f + a.lt);
-    const long blocks = 8L * gx * gy_per_xcd * chunks;
+    const long blocks = 8L * tiles_per_xcd * chunks;
     if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one PD_TV launch");
-    pd_zmarch_xk_kernel<T, NONNEG, ANISO, FAST, K, RY, WX, WY, LAG, LREG><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd);
+    pd_zmarch_xk_kernel<T, NONNEG, ANISO, FAST, K, RY, WX, WY, LAG, LREG><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, tiles_per_xcd);
     return TOMO_OK;
 }

@@ -130,9 +130,11 @@ __global__ __launch_bounds__(256) void bp_tiled_kernel(BpArgs a)
     // XCD-aware numbering: workgroup b lands on XCD b%8; give each XCD its own z-batch stream
     const int ntiles = a.ntx * a.nty;
     const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
-    const int zb = (q / ntiles) * 8 + xcd;
-    if (zb >= a.nzb) return;  // uniform for the workgroup
-    const int tid = q % ntiles;
+    const int per_xcd = (a.nzb * ntiles + 7) >> 3;  // a contiguous eighth of the (z-batch, tile) list per XCD
+    const int wi = xcd * per_xcd + q;
+    if (wi >= a.nzb * ntiles) return;  // uniform for the workgroup
+    const int zb = wi / ntiles;
+    const int tid = wi % ntiles;
     const int tx0 = (tid % a.ntx) * BP_TX, ty0 = (tid / a.ntx) * BP_TY;
     const int z0 = zb * (4 * BP_ZQ);
 
@@ -241,7 +243,7 @@ int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
         a.ntx = ceil_div(a.n, BB_TX);
         a.nty = ceil_div(a.n, BB_TY);
         a.nzb = ceil_div(a.nz, 4 * BB_ZQ);
-        const long blocks = 8L * ceil_div(a.nzb, 8) * a.ntx * a.nty;
+        const long blocks = 8L * (((long)a.nzb * a.ntx * a.nty + 7) / 8);
         if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one BP launch");
         if (lerp8) bp_brick_kernel<EPI, true><<<(unsigned)blocks, 256, 0, st>>>(a);
         else bp_brick_kernel<EPI, false><<<(unsigned)blocks, 256, 0, st>>>(a);
@@ -250,7 +252,7 @@ int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
         a.ntx = ceil_div(a.n, BP_TX);
         a.nty = ceil_div(a.n, BP_TY);
         a.nzb = ceil_div(a.nz, 4 * BP_ZQ);
-        const long blocks = 8L * ceil_div(a.nzb, 8) * a.ntx * a.nty;
+        const long blocks = 8L * (((long)a.nzb * a.ntx * a.nty + 7) / 8);
         if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one BP launch");
         if (lerp8) bp_tiled_kernel<EPI, true><<<(unsigned)blocks, 256, 0, st>>>(a);
         else bp_tiled_kernel<EPI, false><<<(unsigned)blocks, 256, 0, st>>>(a);
@@ -485,7 +487,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
             t.bt = bt;
             t.ngroups = ceil_div(nc, FP_A);
             t.nzb = ceil_div(a.nz, 4);
-            const long blocks_w = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
+            const long blocks_w = 8L * (((long)t.nzb * t.nut * t.ngroups + 7) / 8);
             if (blocks_w > 0x7fffffffL) return -1;
 #define FP_WIDE_LAUNCH(L8, RES)                                                                                        \
     do {                                                                                                               \
@@ -568,7 +570,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 t.bt = 256;
                 t.ngroups = ceil_div(nc, FP_A);
                 t.nzb = ceil_div(a.nz, 4);
-                const long blocks = 8L * ceil_div(t.nzb, 8) * t.nut * t.ngroups;
+                const long blocks = 8L * (((long)t.nzb * t.nut * t.ngroups + 7) / 8);
                 TOMO_REQUIRE(blocks <= 0x7fffffffL, "problem too large for one FP launch");
                 // Windows of up to 1280 columns run the register-prefetch pipeline (double-buffered up to 512 columns,
                 // single-buffered beyond); wider ones (detectors wider than 1024 whose whole-row form does not fit in

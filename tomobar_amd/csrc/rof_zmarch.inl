@@ -39,15 +39,17 @@ __device__ __forceinline__ RofD rof_eval(float u, float u_i1, float u_i2, float 
 }
 
 template <int ND, bool HALF, bool FAST, int RY, int WX, int WY>
-__global__ __launch_bounds__(64 * WX * WY) void rof_zmarch_kernel(RofArgs a, int gx, int gy, int gy_per_xcd, int zchunk)
+__global__ __launch_bounds__(64 * WX * WY) void rof_zmarch_kernel(RofArgs a, int gx, int gy, int tiles_per_xcd, int zchunk)
 {
-    int j = (int)blockIdx.x >> 3;
+    // every XCD owns one contiguous eighth of the row-major (yb, xb) tile list: a band of rows whose halos meet in that
+    // XCD's L2, and the same number of workgroups per XCD whatever gy is (tiles_per_xcd = ceil(gx * gy / 8))
+    const int j = (int)blockIdx.x >> 3;
     const int xcd = (int)blockIdx.x & 7;
-    const int xb = j % gx;
-    j /= gx;
-    const int yb = xcd * gy_per_xcd + (j % gy_per_xcd);
-    const int chunk = j / gy_per_xcd;
-    if (yb >= gy) return;
+    const int tq = xcd * tiles_per_xcd + (j % tiles_per_xcd);
+    const int chunk = j / tiles_per_xcd;
+    if (tq >= gx * gy) return;
+    const int xb = tq % gx;
+    const int yb = tq / gx;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -161,7 +163,7 @@ static int rof_zmarch_launch(const RofArgs &a, hipStream_t st)
 {
     const int nout = a.out_end - a.out_begin;
     const int gx = ceil_div(ceil_div(a.dx, 60), WX), gy = ceil_div(a.dy, WY * RY);
-    const int gy_per_xcd = ceil_div(gy, 8);
+    const int tiles_per_xcd = ceil_div(gx * gy, 8);
     int chunks = 1;
     if (ND == 3) {
         const long waves_xy = (long)gx * gy * WX * WY;
@@ -172,8 +174,8 @@ static int rof_zmarch_launch(const RofArgs &a, hipStream_t st)
     }
     const int zchunk = ceil_div(nout, chunks);
     chunks = ceil_div(nout, zchunk);
-    const long blocks = 8L * gx * gy_per_xcd * chunks;
+    const long blocks = 8L * tiles_per_xcd * chunks;
     if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one ROF_TV launch");
-    rof_zmarch_kernel<ND, HALF, FAST, RY, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, gy_per_xcd, zchunk);
+    rof_zmarch_kernel<ND, HALF, FAST, RY, WX, WY><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, tiles_per_xcd, zchunk);
     return TOMO_OK;
 }
