@@ -445,7 +445,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
         // ---- wide form: one 1024-thread workgroup per detector row (see fp_tiled.inl), one launch per stepping AXIS: a
         // whole-row window does not care about the sign of the detector slope, so the two classes of an axis (adjacent in
         // the order table) are merged -- 37 angles make 5 groups of 8 instead of 3 + 3.  Chosen when the 256-pixel tiles
-        // would stage >= 1.25x what whole rows need (the 12-strided angles of an ordered subset), and it fits in LDS.
+        // would stage at least 0.9x what whole rows need (see `pays` below), and it fits in LDS.
         bool done[4] = {false, false, false, false};
         // try_wide: whole-row form for `nc` angles starting at `off_d` of the order table (one stepping class, or the two
         // sign classes of an axis merged); returns 1 if launched, 0 if the 256-pixel tiles are the better choice, < 0 on error
@@ -458,7 +458,10 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                                            ctx->n, ctx->nu, bt);
             const int wp = wp_cache;
             const double cost_rows = (double)nut_w * ceil_div(nc, FP_A) * wp;
-            const bool pays = cost_tiles >= 1.25 * cost_rows;
+            // measured: with equal staging volume the whole-row form is still the faster one (one workgroup per CU streams rows
+            // through a deep prefetch pipeline; BASELINE configs[3], 1500 dense angles at 2048: 0.59 -> 0.51 s per ADMM
+            // iteration), so it is taken whenever it does not stage clearly MORE than the 256-pixel tiles
+            const bool pays = cost_tiles >= 0.9 * cost_rows;
             const int passes_w = ceil_div(wp, bt);
             // rows per chunk: 4 (or 2) double-buffered rows up to two column passes; detectors wider than 2048
             // (3-5 passes, BASELINE configs[4] is 2560 wide) keep ONE tile (two barriers per chunk) of as many
