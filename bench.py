@@ -151,7 +151,7 @@ def cpu_baseline(args):
     block-diagonal over z, the TV cost is linear in the voxel count)."""
     import numpy as np
     from oracle import tomo_oracle as O
-    cores = os.cpu_count() or 1
+    cores = O.threads()   # OpenMP team of the oracle: the CPUs this process may use (affinity mask / cgroup quota)
     nzs = args.cpu_slices
     angles = np.linspace(0, np.pi, args.angles, endpoint=False)
     P = O.Projector(nzs, args.n, args.n, angles, 0.0, args.os)

@@ -36,6 +36,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORC_FLAG_LERP8 1 /* quantise interpolation weight to 8 fractional bits (NVIDIA texture unit emulation) */
 
@@ -499,3 +502,24 @@ void orc_roftv_step(const float *in, const float *Ui, float *Uo, int dx, int dy,
 }
 
 int orc_abi_version(void) { return 1; }
+
+/* Thread count of the OpenMP loops above.  The host may show far more logical CPUs than its cgroup quota lets the
+ * process use (a 256-thread box with a 16-CPU quota): 256 spinning threads on 16 CPUs' worth of time turn a 0.3 s
+ * call into 50 s.  tomo_oracle.py sets this to the usable CPU count when OMP_NUM_THREADS is not given. */
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -64,7 +64,41 @@ def lib():
         _LIB.orc_roftv.restype = C.c_int
         _LIB.orc_round_half.argtypes = [C.c_float]
         _LIB.orc_round_half.restype = C.c_float
+        _LIB.orc_set_threads.argtypes = [C.c_int]
+        _LIB.orc_set_threads.restype = None
+        _LIB.orc_max_threads.restype = C.c_int
+        if "OMP_NUM_THREADS" not in os.environ:
+            _LIB.orc_set_threads(usable_cpus())
     return _LIB
+
+
+def usable_cpus() -> int:
+    """CPUs this process can actually use: the affinity mask capped by the cgroup CPU quota (a container may show 256
+    logical CPUs and grant 16 CPUs' worth of time; an OpenMP team of 256 on that quota is ~100x slower than one of 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if q != "max":
+            quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:                                                               # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
+def threads() -> int:
+    return int(lib().orc_max_threads())
 
 
 def _fptr(a):
