@@ -446,6 +446,9 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
         // whole-row window does not care about the sign of the detector slope, so the two classes of an axis (adjacent in
         // the order table) are merged -- 37 angles make 5 groups of 8 instead of 3 + 3.  Chosen when the 256-pixel tiles
         // would stage at least 0.9x what whole rows need (see `pays` below), and it fits in LDS.
+        // measured at 384..640-wide detectors (tools/kernel_bench.py): the whole-row form is 7-37 % faster than 256-pixel
+        // tiles there as well, so it is considered from 128 pixels up (it used to start at 768)
+        constexpr int FP_WIDE_MIN_NU = 128;
         bool done[4] = {false, false, false, false};
         // try_wide: whole-row form for `nc` angles starting at `off_d` of the order table (one stepping class, or the two
         // sign classes of an axis merged); returns 1 if launched, 0 if the 256-pixel tiles are the better choice, < 0 on error
@@ -519,7 +522,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
         {
             size_t axis_off = s.table_offset;
             const int nut = ceil_div(a.nu, 256);
-            for (int d = 0; d < 2 && g_variant_fp == 0 && a.nu >= 768; ++d) {
+            for (int d = 0; d < 2 && g_variant_fp == 0 && a.nu >= FP_WIDE_MIN_NU; ++d) {
                 const int nc0 = s.n_class[2 * d], nc1 = s.n_class[2 * d + 1], nc = nc0 + nc1;
                 const size_t off_d = axis_off;
                 axis_off += nc;
