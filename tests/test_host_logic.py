@@ -176,3 +176,22 @@ def test_bench_ranks_take_arguments_from_environment(monkeypatch):
     assert (a.gpus, a.n, a.nz, a.strong) == (2, 256, 32, True)
     monkeypatch.delenv("RANK")
     assert bench.parse().gpus == 1   # a plain run ignores a stale variable
+
+
+def test_oracle_thread_team_follows_the_usable_cpus(oracle, monkeypatch):
+    """The oracle's OpenMP team is sized to the CPUs the process may use (affinity mask capped by the cgroup quota), not
+    to the logical CPU count of the host."""
+    import os
+    n = oracle.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    if "OMP_NUM_THREADS" not in os.environ:
+        assert oracle.threads() == n
+    real_open = open
+
+    def fake_open(path, *a, **k):   # a container that shows every CPU and grants two
+        if path == "/sys/fs/cgroup/cpu.max":
+            import io
+            return io.StringIO("200000 100000\n")
+        return real_open(path, *a, **k)
+    monkeypatch.setattr("builtins.open", fake_open)
+    assert oracle.usable_cpus() == min(2, len(os.sched_getaffinity(0)))
