@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define TOMO_ABI_VERSION 1
+/* raised whenever an entry point is added or a signature changes (tomobar_amd/_lib.py checks it at load) */
+#define TOMO_ABI_VERSION 2
 
 enum {
     TOMO_OK = 0,
@@ -174,6 +175,12 @@ int tomo_momentum(const float *x_dev, const float *xold_dev, float *xt_dev, floa
  * tomo_fp3d* call on xt_dev (and only that one) skips its own transpose pass.  Same value as tomo_momentum, bit for bit. */
 int tomo_momentum_transposed(tomo_ctx *ctx, const float *x_dev, const float *xold_dev, float *xt_dev, float beta,
                              void *stream);
+/* The transposed copy is a one-shot token keyed on (xt_dev, stream): ANY following tomo_fp3d* call on the context spends
+ * it, whether it can use it or not.  tomo_ctx_invalidate drops it explicitly -- call it when the volume behind xt_dev may
+ * be rewritten or freed before the next forward projection (RecToolsIRCuPy.FISTA does at entry and exit, so a buffer the
+ * allocator hands out again at the same address can never meet a stale copy; methodsIR_CuPy.py:447-475 has no
+ * counterpart: ASTRA re-uploads the volume on every call, astra_base.py:560-606). */
+int tomo_ctx_invalidate(tomo_ctx *ctx);
 int tomo_admm_dual(float *u_dev, const float *z_dev, const float *x_dev, size_t count, void *stream);
 int tomo_axpby(float a, const float *x_dev, float b, float *y_dev, size_t count, void *stream);
 int tomo_scale(float a, const float *x_dev, float *y_dev, size_t count, void *stream);

@@ -76,6 +76,9 @@ class OracleTools3D:
     def momentum(self, x, x_old, x_t, beta):
         _put(x_t, _np(x) + np.float32(beta) * (_np(x) - _np(x_old)))
 
+    def invalidate(self):
+        pass
+
     def grad_step(self, res, x_t, x_out, l_inv, nonneg, os_index):
         x = _np(x_t) - np.float32(l_inv) * self.P.bp(np.ascontiguousarray(_np(res)), self._sub(os_index))
         if nonneg:

@@ -290,3 +290,44 @@ def test_osem_against_reference_python_loop(oracle, golden_dir, name):
     want = oracle.circular_mask(oracle.osem(P, sino, alg["iterations"], alg.get("nonnegativity", False), full_reg),
                                 alg.get("recon_mask_radius", 1.0))
     assert np.array_equal(got, want), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("method", ["PD_TV", None])
+def test_fista_repeated_calls_on_one_object_are_bit_identical(oracle, geom, method):
+    """the transposed X_t that the momentum kernel leaves in the projector context is a one-shot
+    token; it must never survive a FISTA call.  Three calls on ONE object with the Lipschitz constant supplied (no power
+    method in between, so the allocator hands the next call's X_t the address of the last one's): original data, other
+    data, original data again -- calls 1 and 3 must agree bit for bit with each other and with the oracle."""
+    os_n = 4
+    rt = make(geom, os_number=os_n)
+    P = oracle.Projector(geom["nz"], geom["n"], geom["n"], geom["angles"], 0.0, os_n)
+    Lc = 2.0e4
+    reg = None if method is None else {"method": "PD_TV", "regul_param": 0.002, "iterations": 6, "methodTV": 0,
+                                       "PD_LipschitzConstant": 12.0}
+    alg = {"iterations": 2, "lipschitz_const": Lc, "nonnegativity": True, "recon_mask_radius": None}
+    want = oracle.fista(P, geom["sino"], 2, Lc, True, reg)
+    outs = []
+    for scale in (1.0, -3.0, 1.0):
+        d = data_dict(geom)
+        d["projection_data"] = d["projection_data"] * scale
+        r = None if reg is None else {"method": "PD_TV", "regul_param": 0.002, "iterations": 6}
+        outs.append(host(rt.FISTA(d, dict(alg), r)))
+    assert np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[0], want), float(np.abs(outs[0] - want).max())
+    # and the explicit entry point: an armed token is dropped by tomo_ctx_invalidate / spent by an unrelated projection
+    A = rt.Atools
+    x = torch.rand(A.vol_shape(), device="cuda")
+    xo = torch.rand(A.vol_shape(), device="cuda")
+    xt = torch.empty_like(x)
+    A.momentum(x, xo, xt, 0.5)
+    ref = host(A.forward(xt, 1))                 # uses the token
+    xt.mul_(2.0)                                 # same address, new contents
+    assert np.array_equal(host(A.forward(xt, 1)), 2.0 * ref)   # token spent: fresh transpose (power of two is exact)
+    A.momentum(x, xo, xt, 0.5)
+    A.invalidate()
+    xt.mul_(2.0)
+    assert np.array_equal(host(A.forward(xt, 1)), 2.0 * ref)
+    A.momentum(x, xo, xt, 0.5)
+    A.forward(xo, 0)                             # another volume's projection spends the token too
+    xt.mul_(2.0)
+    assert np.array_equal(host(A.forward(xt, 1)), 2.0 * ref)

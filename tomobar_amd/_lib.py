@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtomo_mi355x.so")
 
 OK, E_INVALID, E_RUNTIME, E_NOMEM, E_NODEVICE = 0, 1, 2, 3, 4
+ABI_VERSION = 2  # TOMO_ABI_VERSION of include/tomo_mi355x.h (tests/test_host_logic.py keeps the two in step)
 FLAG_LERP8 = 1
 FID = {"LS": 0, "PWLS": 1, "KL": 2, "RATIO": 3}
 
@@ -53,6 +54,7 @@ SIGNATURES = {
     "tomo_bp3d_admm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _f, _i, _vp]),
     "tomo_momentum": (_i, [_vp, _vp, _vp, _f, _sz, _vp]),
     "tomo_momentum_transposed": (_i, [_vp, _vp, _vp, _vp, _f, _vp]),
+    "tomo_ctx_invalidate": (_i, [_vp]),
     "tomo_admm_dual": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "tomo_axpby": (_i, [_f, _vp, _f, _vp, _sz, _vp]),
     "tomo_scale": (_i, [_f, _vp, _vp, _sz, _vp]),
@@ -111,12 +113,17 @@ def lib():
                 f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
                 "Build it with `make -C tomobar_amd/csrc` or `__graft_entry__.build()`.")
         handle = C.CDLL(LIB_PATH)
+        missing = [name for name in SIGNATURES if not hasattr(handle, name)]
+        if missing:
+            raise ImportError(f"{LIB_PATH} is stale: it does not export {missing[:4]}{'...' if len(missing) > 4 else ''}; "
+                              "rebuild it (make -C tomobar_amd/csrc)")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.tomo_abi_version() != 1:
-            raise ImportError("libtomo_mi355x.so ABI version mismatch")
+        if handle.tomo_abi_version() != ABI_VERSION:
+            raise ImportError(f"libtomo_mi355x.so has ABI version {handle.tomo_abi_version()}, this package binds "
+                              f"version {ABI_VERSION}: rebuild it (make -C tomobar_amd/csrc)")
         _lib = handle
     return _lib
 

@@ -72,11 +72,16 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
     const bool x_last = (x == dx - 1);
     const bool x_has_prev = (x > 0);
     const bool emit_lane = (lane >= K) && (lane <= 63 - K) && (x < dx);
-    const int xc = min(max(x, 0), dx - 1);
+    int xc = min(max(x, 0), dx - 1);
+    if (a.probe & 2) xc = min(max(xc, xb * WX * (64 - 2 * K)), min((xb + 1) * WX * (64 - 2 * K), dx) - 1);
 
     unsigned off[NR];  // byte offsets of row slots -K..RY+K-1 (clamped into the volume)
 #pragma unroll
-    for (int i = 0; i < NR; ++i) off[i] = (unsigned)(min(max(y0 + i - K, 0), dy - 1) * dx + xc) * 4u;
+    for (int i = 0; i < NR; ++i) {
+        int yy = min(max(y0 + i - K, 0), dy - 1);
+        if (a.probe & 1) yy = min(max(yy, yb * WY * RY), min((yb + 1) * WY * RY, dy) - 1);
+        off[i] = (unsigned)(yy * dx + xc) * 4u;
+    }
     const PlaneIO io{(int)(sz * 4)};  // plane-relative buffer addressing, see tv_kernels.hip
     auto ldf = [&](const float *base, unsigned boff) { return io.ldf(base, boff); };
     auto ldd = [&](const T *base, unsigned boff) { return io.ldd(base, boff); };

@@ -388,6 +388,7 @@ int fp_scratch(tomo_ctx *ctx)
 {
     const size_t need = (size_t)ctx->nz * ctx->n * ctx->n * sizeof(float);
     if (ctx->scratch_bytes < need) {
+        ctx->volT_valid = false;
         if (ctx->scratch) { TOMO_HIP(hipDeviceSynchronize()); TOMO_HIP(hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
         TOMO_HIP(hipMalloc(&ctx->scratch, need));
         ctx->scratch_bytes = need;
@@ -402,9 +403,14 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
     TOMO_REQUIRE(vol != nullptr && out != nullptr, "NULL data pointer");
     TOMO_REQUIRE(subset < ctx->os, "subset %d out of range (OS_number %d)", subset, ctx->os);
     tomo_subset &s = (subset < 0 || ctx->os == 1) ? ctx->subsets[0] : ctx->subsets[1 + subset];
+    hipStream_t st = as_stream(stream);
+    // the transposed copy tomo_momentum_transposed left behind is a ONE-SHOT token: whatever this call does with it
+    // (use it, find it belongs to another volume / stream, return early), it is spent before anything else happens
+    const bool ready = ctx->volT_valid && ctx->volT_of == vol && ctx->volT_stream == st && ctx->scratch != nullptr;
+    ctx->volT_valid = false;
+    ctx->volT_of = nullptr;
     if (s.size == 0) return TOMO_OK;
     TOMO_ON_DEVICE(ctx->device);
-    hipStream_t st = as_stream(stream);
     FpArgs a;
     a.vol = vol;
     a.volT = nullptr;
@@ -412,7 +418,6 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
         int rc = fp_scratch(ctx);
         if (rc != TOMO_OK) return rc;
         // tomo_momentum_transposed has just written this volume's transposed copy: use it once, skip the pass
-        const bool ready = ctx->volT_valid && ctx->volT_of == vol;
         if (!ready) {
             dim3 tg(ceil_div(ctx->n, 32), ceil_div(ctx->n, 32), ctx->nz);
             transpose_inplane_kernel<<<tg, 256, 0, st>>>(vol, (float *)ctx->scratch, ctx->n);
@@ -420,7 +425,6 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
         }
         a.volT = (const float *)ctx->scratch;
     }
-    ctx->volT_valid = false;  // one use only: the volume may change before the next call
     a.tab = ctx->dev_table + s.table_offset;
     a.nz = ctx->nz; a.n = ctx->n; a.nu = ctx->nu; a.na = s.size; a.na_full = ctx->na;
     a.out = out; a.b = b; a.w = w; a.fidelity = fidelity; a.gathered = gathered;
@@ -674,7 +678,16 @@ extern "C" int tomo_momentum_transposed(tomo_ctx *ctx, const float *x_dev, const
     momentum_transpose_kernel<<<tg, 256, 0, as_stream(stream)>>>(x_dev, xold_dev, xt_dev, (float *)ctx->scratch, beta, ctx->n);
     TOMO_LAUNCH_CHECK();
     ctx->volT_of = xt_dev;
+    ctx->volT_stream = as_stream(stream);
     ctx->volT_valid = true;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_ctx_invalidate(tomo_ctx *ctx)
+{
+    TOMO_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->volT_valid = false;
+    ctx->volT_of = nullptr;
     return TOMO_OK;
 }
 

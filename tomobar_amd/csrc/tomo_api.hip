@@ -22,6 +22,7 @@ int tomo_fail(int code, const char *fmt, ...)
 
 // test / A-B switches (tomo_set_variant), per host thread: one thread's choice never changes what another launches
 thread_local int g_variant_bp = 0, g_variant_fp = 0, g_variant_pdtv = 0, g_variant_roftv = 0;
+thread_local int g_probe = 0;  // measurement-only switches of tools/ (tomo_set_variant("probe", bits)); 0 in every product path
 
 extern "C" int tomo_abi_version(void) { return TOMO_ABI_VERSION; }
 extern "C" const char *tomo_last_error(void) { return g_err; }
@@ -48,6 +49,7 @@ extern "C" int tomo_set_variant(const char *kernel, int variant)
     else if (k == "fp") g_variant_fp = variant;
     else if (k == "pdtv") g_variant_pdtv = variant;
     else if (k == "roftv") g_variant_roftv = variant;
+    else if (k == "probe") g_probe = variant;
     else return tomo_fail(TOMO_E_INVALID, "unknown kernel '%s'", kernel);
     return TOMO_OK;
 }
@@ -180,6 +182,8 @@ extern "C" int tomo_ctx_destroy(tomo_ctx *ctx)
 extern "C" int tomo_ctx_release_scratch(tomo_ctx *ctx)
 {
     TOMO_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->volT_valid = false;  // the transposed copy lives in the scratch that is about to go
+    ctx->volT_of = nullptr;
     if (ctx->scratch) {
         TOMO_ON_DEVICE(ctx->device);
         TOMO_HIP(hipDeviceSynchronize());

@@ -63,6 +63,7 @@ struct tomo_ctx {
     size_t scratch_bytes = 0;
     const float *volT_of = nullptr;           // volume whose transposed copy `scratch` holds (tomo_momentum_transposed)
     bool volT_valid = false;                  // ... valid for exactly the next forward projection of that volume
+    hipStream_t volT_stream = nullptr;        // ... on the stream the copy was written on (another stream would race it)
     std::string last_fp_path, last_bp_path;   // which kernels the last FP / BP call ran (tomo_ctx_kernel_path)
 };
 
@@ -98,6 +99,7 @@ void tomo_fbp_cache_release(int device);      // cached hipFFT plans / filter ta
 
 // kernel-variant switches (tomo_set_variant)
 extern thread_local int g_variant_bp, g_variant_fp, g_variant_pdtv, g_variant_roftv;
+extern thread_local int g_probe;
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

@@ -137,6 +137,7 @@ struct PdArgs {
     float inv1lt;     // 1 / (1 + lt), relaxed-arithmetic kernels only
     int p_in_zero = 0;   // pd_zmarch_xk: the input duals are all zero (first launch of a prox): do not read them
     int p_out_skip = 0;  // pd_zmarch_xk: do not store the output duals (last launch of a prox)
+    int probe = 0;       // measurement only (tools/pd_halo_probe.py): 1 = alias the y halo rows, 2 = the x halo lanes onto the workgroup's own tile
 };
 
 // ------------------------------------------------------------------------------------------ PD variant 1
@@ -525,6 +526,7 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
         a.dx = dx; a.dy = dy; a.planes = dz; a.out_begin = 0; a.out_end = dz;
         a.first_is_edge = 1; a.last_is_edge = 1;
         a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = dz;
+        a.probe = g_probe;
         if (pair) rc = half ? pd_multi_launch<__half>(a, step, methodTV, nonneg, v, st) : pd_multi_launch<float>(a, step, methodTV, nonneg, v, st);
         else rc = pd_iter(a, nd, methodTV, nonneg, half, st);
         if (rc != TOMO_OK) return rc;

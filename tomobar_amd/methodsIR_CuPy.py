@@ -190,7 +190,11 @@ class RecToolsIRCuPy:
         X_grad = self._new_vol() if has_prox else None
         X_prox = self._new_vol() if has_prox else None
 
-        for _ in range(a["iterations"]):
+        # the transposed X_t that A.momentum leaves in the projector context is a one-shot token for the NEXT residual of
+        # this loop; nothing of it may survive this call (a later call's X_t can land at the same address)
+        A.invalidate()
+        n_sub_total = a["iterations"] * self.OS_number
+        for it_no in range(a["iterations"]):
             for sub_ind in range(self.OS_number):
                 sub = sub_ind if use_os else None
                 t_old = t
@@ -213,11 +217,15 @@ class RecToolsIRCuPy:
                 else:
                     A.grad_step(res[sub], X_t, X_grad, L_inv, nonneg, sub)
                     prox_regul(self, X_grad, r, out=X_prox)
-                    A.momentum(X_prox, X, X_t, beta)   # also leaves X_t transposed for the next forward projection
+                    if it_no * self.OS_number + sub_ind + 1 < n_sub_total:
+                        # also leaves X_t transposed for the next forward projection; after the LAST sub-iteration X_t
+                        # is never read again (the reference still computes it, methodsIR_CuPy.py:475): skipped
+                        A.momentum(X_prox, X, X_t, beta)
                     X, X_prox = X_prox, X
                 if use_ring:
                     # r <- soft(r, lambda) ;  r_x = r + beta (r - r_old)
                     A.ring_update(r_cur, r_old, r_x, float32(ring_lambda), beta)
+        A.invalidate()
         return self._finalise(X, a)
 
     # ------------------------------------------------------------------ ADMM

@@ -294,6 +294,10 @@ class HipTools3D:
             L.check(L.lib().tomo_momentum_transposed(self._ctx, ops.ptr(x), ops.ptr(x_old), ops.ptr(x_t), float(beta),
                                                      ops.stream_ptr(x)))
 
+    def invalidate(self):
+        """Drop the one-shot transposed copy ``momentum`` may have left in the context (see tomo_ctx_invalidate)."""
+        L.check(L.lib().tomo_ctx_invalidate(self._ctx))
+
     def grad_step(self, res, x_t, x_out, l_inv, nonneg, os_index):
         res = self._adjoint_in(res, os_index)
         with torch.cuda.device(self._device):
