@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- FISTA-OS (+PD_TV) outer iterations per second on MI355X, BASELINE.json's metric.
 
-    python bench.py --gpus N --steps K --warmup W [--strong]
+    python bench.py --gpus N --steps K --warmup W [--config cfg1|cfg2|cfg3|cfg3-share|cfg5|cfg5-share] [--strong]
 
 N > 1: when the process was not started by a launcher (no RANK in the environment) it re-executes itself as
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`,
@@ -9,23 +9,26 @@ one rank per GPU over RCCL (backend "nccl"); started under a launcher it reads R
 node shows fewer GPUs than ranks the ranks share devices and the halo exchange is staged through the host with gloo
 (a functional dry run of the multi-rank path, flagged `"oversubscribed": true`; never a performance number).
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on that fits one GPU): a 3D phantom of
+Default workload (BASELINE.json configs[2], the configuration the metric is quoted on that fits one GPU): a 3D phantom of
 1024 slices of 1024^2, 900 angles over [0, pi), detector 1024 wide, ordered-subsets FISTA with 12 subsets, PD_TV
 proximal step (30 inner iterations, float32 duals), non-negativity.  One "step" = one OUTER iteration = 12
 sub-iterations (fused-residual forward projection, back projection with the gradient-step epilogue, 30 PD_TV inner
-iterations, momentum).  Data are synthetic (ellipsoid phantom forward-projected on the GPU + Gaussian noise, seed 0)
-and resident in HBM before the timed region.
+iterations, momentum).  Data are synthetic and resident in HBM before the timed region: the ANALYTIC line integrals of
+the ellipsoid phantom, evaluated on the GPU, with Poisson noise.  `--config` selects the other BASELINE
+configurations (PRESETS below); explicit --n/--nz/... flags override a preset and the workload string always states
+what actually ran.
 
 Multi-GPU: the volume / sinogram are sharded into z-slabs; the projector pair is block-diagonal over z so the only
-exchange is the two-plane TV halo (tomobar_amd.slab, RCCL send/recv between z-neighbours) and the scalar reductions.
-  weak   (default): one 1024-slice slab PER RANK; `value` = slab-iterations/s (at N=1 exactly FISTA-OS outer
-                    iterations/s of the 1024^3 problem).
-  strong (--strong): the 1024 slices are split over the N ranks (balanced); `value` = outer iterations/s of the one
-                    1024^3 problem.
+exchange is the three-plane TV halo (tomobar_amd.slab: packed, one RCCL send/recv per neighbour and launch) and the
+scalar reductions.
+  weak   (default): one --nz-slice slab PER RANK; `value` = slab-iterations/s (at N=1 exactly outer iterations/s).
+  strong (--strong): the --nz slices are split over the N ranks (balanced); `value` = outer iterations/s of the ONE
+                    problem -- `--strong --config cfg5` is the north-star workload (2560^2 x 2160, 1800 angles).
+Per-rank exchange statistics (messages, bytes, host time posting / waiting, compute-stream stall) are in `halo`.
 
 One JSON line is printed by rank 0 (see the contract in the task statement) with two extra objects: `roofline`
 (dominant kernel by time in the timed region, measured with HIP events on the launch stream by the library itself)
-and `cpu_baseline` (the CPU oracle, oracle/tomo_oracle.c, on the host cores for a bounded z-subsample).
+and `cpu_baseline` (the CPU oracle, oracle/tomo_oracle.c, on the host cores for a z-subsample of the SAME sinogram).
 """
 import argparse
 import ctypes as C
@@ -42,6 +45,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy ceiling)
 FP32_VALU_PEAK_TFLOPS = 157.3  # same guide: vector f32 peak (the issue roof of the 2-tap gathers in BP / FP)
+LDS_PEAK_BPS = 256.0 * 256 * 2.4e9  # same guide, LDS: ds_read_b128 256 B/clk/CU x 256 CUs x 2.4 GHz = 157 TB/s
 
 # source files whose content decides the HBM traffic of each kernel class (profiles/pmc_traffic.json is only valid
 # for the sources it was measured on)
@@ -67,26 +71,56 @@ PHANTOM_ELLIPSOIDS = [
 ]
 
 
+# BASELINE.json configs[1..4] (configs[0] is the CPU plumbing case, tests/test_cfg1_cpu.py).  "-share" = the slab ONE GPU
+# holds when the configuration is sharded over the number of GPUs BASELINE names (4 for configs[3], 8 for configs[4]).
+PRESETS = {
+    "cfg1": dict(n=256, nz=256, angles=360, os=1, reg="none", method="FISTA", baseline="configs[1]"),
+    "cfg2": dict(n=1024, nz=1024, angles=900, os=12, reg="PD_TV", inner=30, method="FISTA", baseline="configs[2]"),
+    "cfg3": dict(n=2048, nz=1024, angles=1500, os=1, reg="ROF_TV", inner=20, method="ADMM", baseline="configs[3]"),
+    "cfg3-share": dict(n=2048, nz=256, angles=1500, os=1, reg="ROF_TV", inner=20, method="ADMM",
+                       baseline="configs[3], one GPU's slab of 4"),
+    "cfg5": dict(n=2560, nz=2160, angles=1800, os=12, reg="PD_TV", inner=30, ring=1e-4, method="FISTA",
+                 baseline="configs[4]"),
+    "cfg5-share": dict(n=2560, nz=270, angles=1800, os=12, reg="PD_TV", inner=30, ring=1e-4, method="FISTA",
+                       baseline="configs[4], one GPU's slab of 8"),
+}
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2)
     p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--config", default=None, choices=sorted(PRESETS), help="BASELINE configuration preset (default cfg2)")
     p.add_argument("--strong", action="store_true", help="strong scaling: --nz slices in total, split over the ranks")
-    p.add_argument("--n", type=int, default=1024, help="slice size N = detector width")
-    p.add_argument("--nz", type=int, default=1024, help="slices per GPU slab (weak) / in total (--strong)")
-    p.add_argument("--angles", type=int, default=900)
-    p.add_argument("--os", type=int, default=12)
-    p.add_argument("--inner", type=int, default=30, help="TV inner iterations")
-    p.add_argument("--reg", default="PD_TV", choices=["PD_TV", "ROF_TV", "none"])
+    p.add_argument("--n", type=int, default=None, help="slice size N = detector width")
+    p.add_argument("--nz", type=int, default=None, help="slices per GPU slab (weak) / in total (--strong)")
+    p.add_argument("--angles", type=int, default=None)
+    p.add_argument("--os", type=int, default=None)
+    p.add_argument("--inner", type=int, default=None, help="TV inner iterations")
+    p.add_argument("--reg", default=None, choices=["PD_TV", "ROF_TV", "none"])
+    p.add_argument("--method", default=None, choices=["FISTA", "ADMM"])
     p.add_argument("--half", action="store_true", help="binary16 dual fields")
-    p.add_argument("--ring", type=float, default=0.0, help="Group-Huber ring term: ringGH_lambda (BASELINE configs[4])")
+    p.add_argument("--ring", type=float, default=None, help="Group-Huber ring term: ringGH_lambda (BASELINE configs[4])")
     p.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     p.add_argument("--cpu-slices", type=int, default=8)
     if len(sys.argv) == 1 and "TOMO_BENCH_ARGV" in os.environ and "RANK" in os.environ:  # rank started by self_launch()
-        return p.parse_args(json.loads(os.environ["TOMO_BENCH_ARGV"]))
-    return p.parse_args()
+        args = p.parse_args(json.loads(os.environ["TOMO_BENCH_ARGV"]))
+    else:
+        args = p.parse_args()
+    preset = dict(PRESETS[args.config or "cfg2"])
+    args.baseline = preset.pop("baseline")
+    overridden = []
+    for key, val in {**dict(inner=30, ring=0.0), **preset}.items():
+        if getattr(args, key) is None:
+            setattr(args, key, val)
+        elif getattr(args, key) != val and key in preset:
+            overridden.append(key)
+    if args.half:
+        overridden.append("half")
+    args.overridden = overridden   # the workload string names the BASELINE config only when nothing was overridden
+    return args
 
 
 def free_port():
@@ -145,29 +179,62 @@ def source_hash(kernel):
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(args):
-    """The CPU oracle (port of the reference algorithm; ASTRA / CuPy are not installable here) on the host cores:
-    one FISTA-OS outer iteration on a z-subsample of the same geometry; scaled linearly in Nz (A and A^T are
-    block-diagonal over z, the TV cost is linear in the voxel count)."""
+def analytic_sinogram(n, nz_total, z_begin, nz, angles, device):
+    """Line integrals of the ellipsoid phantom on the engine's geometry, evaluated on the GPU: [nz, na, n] float32 in voxel
+    units (analytic ellipsoid sinogram; same formula as oracle.shepp_logan_sino).  torch is plumbing here:
+    this is input data, not part of the measured path."""
+    import numpy as np
+    import torch
+    na = len(angles)
+    th = torch.as_tensor(np.asarray(angles), dtype=torch.float64, device=device).view(1, na, 1)
+    s = ((torch.arange(n, device=device, dtype=torch.float64) - n / 2 + 0.5) / (n / 2)).view(1, 1, n)
+    out = torch.empty((nz, na, n), dtype=torch.float32, device=device)
+    for zb in range(0, nz, 32):                                                     # bounded float64 temporaries
+        ze = min(zb + 32, nz)
+        zs = ((torch.arange(z_begin + zb, z_begin + ze, device=device, dtype=torch.float64) - nz_total / 2 + 0.5)
+              / (nz_total / 2)).view(ze - zb, 1, 1)
+        acc = torch.zeros((ze - zb, na, n), dtype=torch.float64, device=device)
+        for A, a, b, c, x0, y0, z0, phi in PHANTOM_ELLIPSOIDS:
+            p = float(np.deg2rad(phi))
+            k2 = torch.clamp(1.0 - ((zs - z0) / c) ** 2, min=0.0)                   # section scale^2, [nz,1,1]
+            r2 = (a * torch.cos(th - p)) ** 2 + (b * torch.sin(th - p)) ** 2        # [1,na,1]
+            d = s - (x0 * torch.cos(th) + y0 * torch.sin(th))                       # [1,na,n]
+            disc = torch.clamp(r2 * k2 - d * d, min=0.0)
+            acc += A * 2.0 * a * b * torch.sqrt(disc) / r2
+        out[zb:ze] = (acc * (n / 2)).to(torch.float32)
+    return out
+
+
+def cpu_baseline(args, sino_dev, lc):
+    """The CPU oracle (port of the reference algorithm; ASTRA / CuPy are not installable here) on the host cores: one
+    outer iteration of the same loop on a z-subsample of the SAME sinogram with the same Lipschitz constant, scaled
+    linearly in Nz (A and A^T are block-diagonal over z, the TV cost is linear in the voxel count)."""
     import numpy as np
     from oracle import tomo_oracle as O
     cores = O.threads()   # OpenMP team of the oracle: the CPUs this process may use (affinity mask / cgroup quota)
-    nzs = args.cpu_slices
+    nz = int(sino_dev.shape[0])
+    nzs = min(args.cpu_slices, nz)
+    zsel = np.unique(np.linspace(0, nz - 1, nzs).round().astype(int))
+    nzs = len(zsel)
+    sino = np.ascontiguousarray(sino_dev[zsel.tolist()].cpu().numpy())
     angles = np.linspace(0, np.pi, args.angles, endpoint=False)
     P = O.Projector(nzs, args.n, args.n, angles, 0.0, args.os)
-    rng = np.random.default_rng(0)
-    sino = rng.random((nzs, args.angles, args.n), dtype=np.float32)
     reg = None
     if args.reg != "none":
         reg = {"method": args.reg, "regul_param": 5e-4, "iterations": args.inner, "time_marching_step": 1e-3,
                "PD_LipschitzConstant": 12.0, "methodTV": 0, "half_precision": args.half}
     t0 = time.perf_counter()
-    O.fista(P, sino, 1, 2.0e4, True, reg)
+    if args.method == "ADMM":
+        O.admm(P, sino, 1, lc, 1.0, 1.6, True, reg)
+    elif args.ring > 0.0:
+        O.fista(P, sino, 1, lc, True, reg, ring={"lambda": args.ring, "accelerate": 50})
+    else:
+        O.fista(P, sino, 1, lc, True, reg)
     dt = time.perf_counter() - t0
-    its_full = (1.0 / dt) * (nzs / args.nz)
+    its_full = (1.0 / dt) * (nzs / nz)
     return {"value": its_full, "unit": "iterations/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/tomo_oracle.c (OpenMP, {cores} threads): 1 outer FISTA-OS iteration on {nzs} of "
-                      f"{args.nz} slices ({dt:.1f} s), scaled by {nzs}/{args.nz}"}
+            "sample": f"oracle/tomo_oracle.c (OpenMP, {cores} threads): 1 outer {args.method} iteration on {nzs} of the "
+                      f"{nz} slices of the GPU leg's own sinogram ({dt:.1f} s), scaled by {nzs}/{nz}"}
 
 
 def main():
@@ -228,13 +295,14 @@ def main():
 
     from tomobar_amd import _lib
     from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
-    from tomobar_amd.slab import SlabComm, check_slab_split, slab_bounds
+    from tomobar_amd.slab import GHOST, SlabComm, check_slab_split, pd_launch_plan, slab_bounds
     lib = _lib.lib()
 
     n, na = args.n, args.angles
     if args.strong:
         nz_total = args.nz
-        check_slab_split(nz_total, world)
+        # every rank evaluates the same test before anything is posted: 3D PD_TV keeps GHOST-plane ghosts, ROF_TV two
+        check_slab_split(nz_total, world, min_slices=GHOST if args.reg == "PD_TV" else 2)
         z0, z1 = slab_bounds(nz_total, world, rank)
     else:
         nz_total = args.nz * world
@@ -243,16 +311,24 @@ def main():
     angles = np.linspace(0, np.pi, na, endpoint=False)
     slab = SlabComm(rank, world, device, group=halo_group) if world > 1 else None
     rt = RecToolsIRCuPy(DetectorsDimH=n, DetectorsDimH_pad=0, DetectorsDimV=nz, CenterRotOffset=0.0, AnglesVec=angles,
-                        ObjSize=n, device_projector=dev_index, OS_number=args.os)
+                        ObjSize=n, device_projector=dev_index, OS_number=args.os if args.os > 1 else None)
     if slab is not None:
+        slab.timing = True
         rt.slab = slab
-    # ---- synthetic data, resident in HBM: A(phantom) + noise
-    vol = phantom_slab(n, nz_total, z0, nz, device)
-    sino = rt.Atools.forward(vol)
+    # ---- synthetic data, resident in HBM: analytic line integrals of the ellipsoid phantom, transmission
+    #      Poisson noise (I0 = 2e4 photons per pixel, peak attenuation 3), seed = rank
+    sino = analytic_sinogram(n, nz_total, z0, nz, angles, device)
+    peak = float(sino.max().item())
+    if dist is not None:
+        t = torch.tensor([peak], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        peak = float(t.item())
+    mu, i0 = 3.0 / max(peak, 1e-6), 2.0e4
     gen = torch.Generator(device=device)
     gen.manual_seed(rank)
-    sino += 0.01 * float(n) * torch.randn(sino.shape, generator=gen, device=device, dtype=torch.float32)
-    del vol
+    counts = torch.poisson(i0 * torch.exp(-mu * sino), generator=gen).clamp_(min=1.0)
+    sino = (-(torch.log(counts / i0)) / mu).to(torch.float32).contiguous()
+    del counts
     rt.power_seed = 0
     lc = rt.powermethod({"projection_data": None})
     reg = None
@@ -266,6 +342,9 @@ def main():
             d["ringGH_lambda"] = args.ring
             d["ringGH_accelerate"] = 50.0
         a = {"iterations": iters, "lipschitz_const": lc, "nonnegativity": True}
+        if args.method == "ADMM":
+            a.update({"ADMM_rho_const": 1.0, "ADMM_relax_par": 1.6})
+            return rt.ADMM(d, a, None if reg is None else dict(reg))
         return rt.FISTA(d, a, None if reg is None else dict(reg))
 
     def barrier():
@@ -277,6 +356,13 @@ def main():
     if args.warmup > 0:
         run(args.warmup)
     barrier()
+    if slab is not None:
+        slab.timing_summary()                      # drop the warm-up's events
+        for k in ("exchanges", "messages", "bytes"):
+            slab.stats[k] = 0
+        for k in ("post_host_ms", "wait_host_ms"):
+            slab.stats[k] = 0.0
+        slab._wait_stream_ms = 0.0
     lib.tomo_profile_enable(1)
     t0 = time.perf_counter()
     out = run(args.steps)
@@ -289,30 +375,56 @@ def main():
     prof = {k: prof_read(lib, k) for k in ("pdtv", "roftv", "bp", "fp")}
     lib.tomo_profile_enable(0)
     finite = bool(torch.isfinite(out).all().item())
+    halo = None
+    if dist is not None:
+        mine = dict(rank=rank, slices=nz, **slab.timing_summary())
+        halo = [None] * world
+        dist.all_gather_object(halo, mine)
 
     if rank == 0:
         V = nz * n * n
         sub = -(-na // args.os)
         S_s = nz * sub * n
-        # algorithmic bytes per unit of work; one PD_TV launch may carry two inner iterations,
-        # so its bytes per launch = bytes per iteration x iterations / launches
         sub_its = args.steps * args.os
-        alg_total = {"pdtv": (24 if args.half else 36) * V * args.inner * sub_its, "roftv": 12 * V * args.inner * sub_its,
+        # SURVEY 8d per-iteration figures (bytes one inner iteration / one projector call must move)
+        pd_it = (24 if args.half else 36) * V
+        alg_total = {"pdtv": pd_it * args.inner * sub_its, "roftv": 12 * V * args.inner * sub_its,
                      "bp": 4 * (S_s + V) * sub_its, "fp": 4 * (S_s + V) * sub_its}
+        # COMPULSORY bytes of the launches as executed: a fused PD_TV launch reads U, P1..3, Input and writes U, P1..3
+        # ONCE for its k iterations (the first launch of a prox reads no duals, the last stores none), so the bytes a
+        # launch must move do not grow with k -- the per-iteration figure x k is an equivalent rate, not a roofline
+        comp_total = dict(alg_total)
+        if args.reg == "PD_TV":
+            plan = pd_launch_plan(args.inner, args.half)
+            pb = 2 if args.half else 4
+            per_prox = 0
+            flags = world == 1   # the whole-volume driver tells a three-iteration launch when the duals are zero / unused
+            for i, k in enumerate(plan):
+                rd = 4 + 4 + (0 if (flags and i == 0 and k == 3) else 3 * pb)          # U, Input, P1..3
+                wr = 4 + (0 if (flags and i == len(plan) - 1 and k == 3) else 3 * pb)  # U, P1..3
+                per_prox += (rd + wr) * V
+            comp_total["pdtv"] = per_prox * sub_its
         kernels = {}
-        alg_bytes = {}
         for k, (cnt, ms) in prof.items():
             if cnt:
                 avg = ms / cnt
-                alg_bytes[k] = alg_total[k] / cnt
+                comp = comp_total[k] / cnt
                 kernels[k] = {"launches": cnt, "avg_ms": avg, "total_ms": ms,
-                              "alg_GBps": alg_bytes[k] / avg / 1e6, "frac_hbm": alg_bytes[k] / avg / 1e6 / HBM_PEAK_GBS}
+                              "compulsory_bytes_per_launch": comp,
+                              "GBps": comp / avg / 1e6, "frac_hbm": comp / avg / 1e6 / HBM_PEAK_GBS}
+                if k == "pdtv":
+                    kernels[k]["iterations_per_launch"] = args.inner * sub_its / cnt
+                    kernels[k]["alg_GBps_per_iteration_equiv"] = alg_total[k] / cnt / avg / 1e6
                 if k in ("bp", "fp"):
                     # the projectors are instruction-issue bound (2 FMAs + 2 LDS taps per voxel-angle update), far above
-                    # their HBM time: report them against the f32 vector roof as well (4 flop per update)
-                    tf = 4.0 * V * sub / avg / 1e9
+                    # their HBM time: report them against the f32 vector roof (4 flop per update) and against the LDS
+                    # floor (8 B of ds_read_b128 per update at 256 B/clk/CU x 256 CUs x 2.4 GHz) as well
+                    upd = float(V) * sub
+                    tf = 4.0 * upd / avg / 1e9
                     kernels[k]["valu_TFLOPs"] = tf
                     kernels[k]["frac_valu"] = tf / FP32_VALU_PEAK_TFLOPS
+                    kernels[k]["lds_floor_ms"] = upd * 8.0 / LDS_PEAK_BPS * 1e3
+                    kernels[k]["frac_lds"] = kernels[k]["lds_floor_ms"] / avg
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
         # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/pmc_run.sh;
         # counters cannot be collected from inside this process).  It is reported only when the kernel sources are
@@ -321,7 +433,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             key = "pdtv_half" if (dom == "pdtv" and args.half) else dom
-            if key in pmc and (n, nz) == (1024, 1024):
+            if key in pmc and (n, nz, na, args.os) == (1024, 1024, 900, 12):
                 ent = pmc[key]
                 cur = source_hash(dom)
                 traffic_src = {"measured_on_sources": ent.get("sources_sha16"), "current_sources": cur,
@@ -330,14 +442,15 @@ def main():
                     traffic = ent["traffic_bytes"]
         except (OSError, ValueError):
             pass
-        roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": kernels[dom]["avg_ms"], "launches": kernels[dom]["launches"],
-                "alg_bytes_per_launch": alg_bytes[dom]}
+                "bytes_per_launch": kernels[dom]["compulsory_bytes_per_launch"],
+                "bytes_definition": "compulsory HBM bytes of one launch as executed (SURVEY 8d per-iteration bytes; a "
+                                    "k-iteration fused PD_TV launch moves them once, not k times)"}
         if dom == "pdtv":
-            # a fused PD_TV launch performs several iterations per pass through HBM: `frac` (algorithmic bytes of all its
-            # iterations / time) can exceed 1; the real-traffic rate is the honest companion figure
-            roof["iterations_per_launch"] = args.inner * sub_its / kernels[dom]["launches"]
+            roof["iterations_per_launch"] = kernels[dom]["iterations_per_launch"]
+            roof["alg_GBps_per_iteration_equiv"] = kernels[dom]["alg_GBps_per_iteration_equiv"]
         if traffic is not None:
             roof["traffic_GBps"] = traffic / kernels[dom]["avg_ms"] / 1e6
             roof["frac_traffic"] = roof["traffic_GBps"] / HBM_PEAK_GBS
@@ -345,22 +458,28 @@ def main():
         what = (f"{nz_total} slices of {n}^2 split over {world} z-slab(s)" if args.strong
                 else f"{nz} slices of {n}^2 per GPU; slab-iterations/s over {world} z-slab(s)")
         ring = f"+GH ring term (lambda {args.ring:g})" if args.ring > 0.0 else ""
+        regs = "no regulariser" if args.reg == "none" else f"{args.reg}({args.inner} inner, {'f16' if args.half else 'f32'} duals)"
+        loop = f"{args.method}-OS({args.os} subsets)" if args.os > 1 else args.method
+        tag = f"BASELINE {args.baseline}" if not args.overridden else \
+            f"custom: BASELINE {args.baseline} with {', '.join(args.overridden)} overridden"
         line = {
             "metric": "fista_os_iterations_per_sec", "value": units / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"FISTA-OS({args.os} subsets)+{args.reg}({args.inner} inner, "
-                                   f"{'f16' if args.half else 'f32'} duals){ring}, {na} angles, {what} "
-                                   f"(BASELINE configs[2])",
+            "config": {"workload": f"{loop}+{regs}{ring}, {na} angles, {what} ({tag})",
                        "slices_per_gpu": nz, "n": n, "angles": na, "os_number": args.os, "inner_iterations": args.inner,
-                       "slices_per_sec": args.steps * nz_total / dt, "lipschitz_const": lc, "output_finite": finite,
+                       "method": args.method, "slice_iterations_per_sec": args.steps * nz_total / dt,
+                       "lipschitz_const": lc, "output_finite": finite,
+                       "input": "analytic ellipsoid line integrals + Poisson noise (I0 2e4, peak attenuation 3)",
                        "backend": backend, "oversubscribed": oversubscribed,
                        **({"backend_note": backend_note} if backend_note else {})},
             "roofline": roof, "kernels": kernels,
         }
+        if halo is not None:
+            line["halo"] = halo
         if not args.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args)
+            line["cpu_baseline"] = cpu_baseline(args, sino, lc)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -273,6 +273,22 @@ int tomo_roftv_iter_slab_range(int device, const float *in_dev, const float *u_i
                                int dx, int dy, int nz_local, int lo_planes, int hi_planes, int z_begin, int z_end,
                                float lambda, float tau, int half, void *stream);
 
+/* Halo staging for the z-slab exchange ("tomo_halo_exchange"; the reference scales by independent replicas
+ * only, Demos/methods_IR_legacy/MultiGPU_demo.py:144-190, so there is no call to replace).  The transport itself stays
+ * with the host (torch.distributed / RCCL in tomobar_amd/slab.py, mpi4py or cupy.cuda.nccl for a CuPy caller --
+ * INTEGRATION.md section C); what the library provides is the device side: the planes a neighbour needs -- the last or
+ * first k planes of U, P1, P2, P3 (each contiguous in its own array) -- gathered into ONE contiguous staging buffer and
+ * scattered back, so that an exchange is one send and one receive per neighbour.  Block i occupies
+ * [off_i, off_i + bytes[i]) of the staging buffer with off_0 = 0, off_{i+1} = off_i + round_up(bytes[i], 16);
+ * tomo_halo_staging_bytes returns the total.  At most 8 blocks per call. */
+size_t tomo_halo_staging_bytes(const size_t *bytes, int nblocks);
+int tomo_halo_pack(const void *const *src_dev, const size_t *bytes, int nblocks, void *staging_dev, void *stream);
+int tomo_halo_unpack(const void *staging_dev, void *const *dst_dev, const size_t *bytes, int nblocks, void *stream);
+/* How many PD_TV iterations tomo_pdtv fuses into one launch for float32 (half = 0) / binary16 (half != 0) dual fields under
+ * the calling thread's kernel variant: a slab driver that wants to be launch-for-launch identical to the whole-volume
+ * operator cuts its iterations the same way (tomobar_amd/slab.py: pd_launch_plan) and keeps that many ghost planes. */
+int tomo_pdtv_iters_per_launch(int half);
+
 /* ---------------------------------------------------------------- FBP filter
  * tomo_fbp_filter replaces _filtersinc3D_cupy (tomobar/fourier.py:26-78) and generate_filtersinc
  * (cuda_kernels/generate_filtersync.cu:5-82): every row of `rows` x `nu` float32 values is replaced, in place, by

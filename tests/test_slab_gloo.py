@@ -22,6 +22,13 @@ def _free_port():
     return port
 
 
+def _seams():
+    """CPU stand-ins for the C-ABI calls of tomobar_amd.slab (halo pack / unpack, iterations per launch)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _cpu_backend
+    _cpu_backend.install()
+
+
 def _worker(rank, world, port, case):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -29,6 +36,7 @@ def _worker(rank, world, port, case):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        _seams()
         from oracle import tomo_oracle as O
         from tomobar_amd.slab import SlabComm, pd_tv_slab, rof_tv_slab, slab_bounds
         comm = SlabComm(rank, world)
@@ -45,6 +53,9 @@ def _worker(rank, world, port, case):
             want = O.rof_tv(vol, 0.05, case["iters"], 0.005, case["half"])
             got = rof_tv_slab(mine, comm, 0.05, case["iters"], 0.005, case["half"], step_fn=O.rof_step_slab)
         assert np.array_equal(got.numpy(), want[z0:z1]), (rank, np.abs(got.numpy() - want[z0:z1]).max())
+        # one message each way per neighbour and exchange, whatever the number of arrays (U, P1, P2, P3) it carries
+        st = comm.timing_summary()
+        assert st["messages"] == 2 * st["exchanges"] * (int(comm.has_lo) + int(comm.has_hi)) or world == 1, st
         # scalar reductions used by the power method / PWLS / CGLS
         assert comm.allreduce_sum(float(rank + 1)) == world * (world + 1) / 2
         assert comm.allreduce_max(float(rank)) == world - 1
@@ -137,6 +148,7 @@ def _short_slab_worker(rank, world, port):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        _seams()
         from oracle import tomo_oracle as O
         from tomobar_amd.slab import SlabComm, pd_tv_slab, rof_tv_slab, slab_bounds
         comm = SlabComm(rank, world)
@@ -144,7 +156,6 @@ def _short_slab_worker(rank, world, port):
         mine = torch.zeros((z1 - z0, 4, 6))
         for fn, kw in ((pd_tv_slab, dict(pair_fn=O.pd_pair_slab, step_fn=O.pd_step_slab)),
                        (rof_tv_slab, dict(step_fn=O.rof_step_slab))):
-            comm._validated.clear()
             try:
                 if fn is pd_tv_slab:
                     fn(mine, comm, 0.04, 4, 0, 0, 8.0, False, **kw)
@@ -175,3 +186,44 @@ def test_slab_bounds_cover_volume():
     check_slab_split(16, 8)
     with pytest.raises(ValueError):
         check_slab_split(15, 8)
+
+
+def _two_volumes_worker(rank, world, port):
+    """ONE communicator, two volumes whose balanced splits differ -- 9 slices over 2 ranks is
+    5 + 4, 8 slices is 4 + 4.  With a per-rank cache keyed on the local height rank 1 (4, 4) skipped the second collective
+    while rank 0 (5, 4) entered it: a hang.  The check is now collective on every call."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _seams()
+        from oracle import tomo_oracle as O
+        from tomobar_amd.slab import SlabComm, pd_tv_slab, slab_bounds
+        comm = SlabComm(rank, world)
+        for nz in (9, 8, 9):
+            rng = np.random.default_rng(nz)
+            vol = rng.random((nz, 6, 9)).astype(np.float32)
+            z0, z1 = slab_bounds(nz, world, rank)
+            got = pd_tv_slab(torch.from_numpy(vol[z0:z1].copy()), comm, 0.04, 5, 0, 0, 8.0, False,
+                             pair_fn=O.pd_pair_slab, step_fn=O.pd_step_slab)
+            want = O.pd_tv(vol, 0.04, 5, 0, 0, 8.0, False)
+            assert np.array_equal(got.numpy(), want[z0:z1])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_one_communicator_two_volumes_with_different_splits():
+    mp.start_processes(_two_volumes_worker, args=(2, _free_port()), nprocs=2, join=True, start_method="spawn")
+
+
+def test_launch_plan_follows_the_library_maximum():
+    from tomobar_amd.slab import pd_launch_plan
+    assert pd_launch_plan(30, False, kmax=3) == [3] * 10
+    assert pd_launch_plan(7, False, kmax=3) == [3, 2, 2]
+    assert pd_launch_plan(4, False, kmax=3) == [2, 2]
+    assert pd_launch_plan(5, True, kmax=2) == [2, 2, 1]
+    assert pd_launch_plan(3, False, kmax=1) == [1, 1, 1]

@@ -88,6 +88,10 @@ SIGNATURES = {
                                         _f, _f, _f, _f, _i, _i, _i, _vp]),
     "tomo_roftv_iter_slab": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "tomo_roftv_iter_slab_range": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
+    "tomo_halo_staging_bytes": (_sz, [C.POINTER(_sz), _i]),
+    "tomo_halo_pack": (_i, [C.POINTER(_vp), C.POINTER(_sz), _i, _vp, _vp]),
+    "tomo_halo_unpack": (_i, [_vp, C.POINTER(_vp), C.POINTER(_sz), _i, _vp]),
+    "tomo_pdtv_iters_per_launch": (_i, [_i]),
     "tomo_fbp_filter": (_i, [_i, _vp, _sz, _i, _f, _f, _vp]),
     "tomo_fourier_inv": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _f, _i, _vp]),
     "tomo_host_bp2d": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_d), _d]),

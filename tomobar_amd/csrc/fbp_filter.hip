@@ -64,28 +64,47 @@ std::vector<float> make_filter(int n, float a, float mult)
     return f;
 }
 
-// hipFFT plan pairs per (device, nu, rows) and device filter tables per (device, nu, cutoff, multiplier) are kept
-// between calls (plan creation costs more than the transforms of a small batch); tomo_release_scratch frees them
-struct fbp_plans { hipfftHandle fwd = 0, inv = 0; };
+// hipFFT plan pairs per (device, stream, nu, rows) and device filter tables per (device, nu, cutoff, multiplier) are kept
+// between calls (plan creation costs more than the transforms of a small batch); tomo_release_scratch frees them.
+// The stream is part of the key: a plan owns ONE work area, so two streams must never execute the same plan concurrently
+// (successive calls on one stream are ordered by the stream itself).  At most FBP_MAX_PLANS pairs are kept per process,
+// least recently used first out (every distinct `rows` value is a plan pair with its own work area).
+struct fbp_plans { hipfftHandle fwd = 0, inv = 0; unsigned long long used = 0; };
 std::mutex g_fbp_mu;
-std::map<std::tuple<int, int, size_t>, fbp_plans> g_fbp_plans;
+constexpr size_t FBP_MAX_PLANS = 8;
+unsigned long long g_fbp_tick = 0;
+std::map<std::tuple<int, hipStream_t, int, size_t>, fbp_plans> g_fbp_plans;
 std::map<std::tuple<int, int, float, float>, float *> g_fbp_filters;
 
-int fbp_get_plans(int device, int nu, size_t rows, fbp_plans &out)
+int fbp_get_plans(int device, hipStream_t st, int nu, size_t rows, fbp_plans &out)
 {
-    const auto key = std::make_tuple(device, nu, rows);
+    const auto key = std::make_tuple(device, st, nu, rows);
     auto it = g_fbp_plans.find(key);
-    if (it != g_fbp_plans.end()) { out = it->second; return TOMO_OK; }
+    if (it != g_fbp_plans.end()) { it->second.used = ++g_fbp_tick; out = it->second; return TOMO_OK; }
+    if (g_fbp_plans.size() >= FBP_MAX_PLANS) {
+        auto victim = g_fbp_plans.begin();
+        for (auto jt = g_fbp_plans.begin(); jt != g_fbp_plans.end(); ++jt)
+            if (jt->second.used < victim->second.used) victim = jt;
+        // the victim's last execution may still be running on its stream: hipfftDestroy frees the work area
+        tomo_device_guard guard(std::get<0>(victim->first));
+        (void)hipStreamSynchronize(std::get<1>(victim->first));
+        (void)hipfftDestroy(victim->second.fwd);
+        (void)hipfftDestroy(victim->second.inv);
+        g_fbp_plans.erase(victim);
+    }
     const int nh = nu / 2 + 1;
     int n[1] = {nu};
     fbp_plans p;
     hipfftResult r = hipfftPlanMany(&p.fwd, 1, n, nullptr, 1, nu, nullptr, 1, nh, HIPFFT_R2C, (int)rows);
     if (r == HIPFFT_SUCCESS) r = hipfftPlanMany(&p.inv, 1, n, nullptr, 1, nh, nullptr, 1, nu, HIPFFT_C2R, (int)rows);
+    if (r == HIPFFT_SUCCESS) r = hipfftSetStream(p.fwd, st);
+    if (r == HIPFFT_SUCCESS) r = hipfftSetStream(p.inv, st);
     if (r != HIPFFT_SUCCESS) {  // nothing half-built is kept or leaked
         if (p.fwd) (void)hipfftDestroy(p.fwd);
         if (p.inv) (void)hipfftDestroy(p.inv);
         return tomo_fail(TOMO_E_RUNTIME, "hipfftPlanMany failed: hipfft status %d", (int)r);
     }
+    p.used = ++g_fbp_tick;
     g_fbp_plans[key] = p;
     out = p;
     return TOMO_OK;
@@ -144,15 +163,13 @@ extern "C" int tomo_fbp_filter(int device, float *data_dev, size_t rows, int nu,
     int rc = tomo_arena_get(device, st, ARENA_MAIN, spec_bytes, &base);
     if (rc != TOMO_OK) return rc;
     float2 *spec = (float2 *)base;
-    std::lock_guard<std::mutex> lk(g_fbp_mu);  // a cached plan is bound to one stream at a time
+    std::lock_guard<std::mutex> lk(g_fbp_mu);  // guards the caches; a plan belongs to one (device, stream)
     const float *filt = nullptr;
     rc = fbp_get_filter(device, nu, cutoff, multiplier, &filt);
     if (rc != TOMO_OK) return rc;
     fbp_plans p;
-    rc = fbp_get_plans(device, nu, rows, p);
+    rc = fbp_get_plans(device, st, nu, rows, p);
     if (rc != TOMO_OK) return rc;
-    TOMO_FFT(hipfftSetStream(p.fwd, st));
-    TOMO_FFT(hipfftSetStream(p.inv, st));
     TOMO_FFT(hipfftExecR2C(p.fwd, data_dev, (hipfftComplex *)spec));
     size_t total = rows * (size_t)nh;
     size_t grid = (total + 255) / 256;

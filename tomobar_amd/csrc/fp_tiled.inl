@@ -26,6 +26,7 @@ struct FpTiledArgs {
     int wpitch;              // LDS pitch (float4 units) per staged row, <= 256 * passes <= 1024
     int nut, ngroups, nzb;   // detector tiles, angle groups, slice quads
     int bt;                  // whole-row form: detector pixels per tile = threads launched (a multiple of 64, <= 1024)
+    int probe;               // measurement only (tools/fp_stage_probe.py): 16 = skip the staging (global loads + LDS writes)
 };
 
 // BT = workgroup size = detector pixels per workgroup.  256: several workgroups per CU.  1024: the workgroup spans the
@@ -139,21 +140,28 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
     };
 
     const int nchunks = (n + KC - 1) / KC;
-    prefetch(0);
+    const bool stage = !(a.probe & 16);  // uniform; false only in the staging-cost measurement (results are garbage then)
+    if (!stage) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) pre[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (stage) prefetch(0);
     for (int c = 0; c < nchunks; ++c) {
         float4 *tile = (c & 1) ? tile1 : tile0;
         if (!DB) __syncthreads();  // every wave is past the sampling of chunk c-1 (same buffer)
+        if (stage) {
 #pragma unroll
-        for (int r = 0; r < KC; ++r)
+            for (int r = 0; r < KC; ++r)
 #pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
-                const int j = tid + bt * p;
-                if (p == 0 || __builtin_amdgcn_readfirstlane(j - (tid & 63)) < a.wpitch)
-                    if (j < a.wpitch) tile[r * a.wpitch + j] = pre[r * PASSES + p];
-            }
+                for (int p = 0; p < PASSES; ++p) {
+                    const int j = tid + bt * p;
+                    if (p == 0 || __builtin_amdgcn_readfirstlane(j - (tid & 63)) < a.wpitch)
+                        if (j < a.wpitch) tile[r * a.wpitch + j] = pre[r * PASSES + p];
+                }
+        }
         __syncthreads();  // chunk c staged; every wave is past the sampling of chunk c-1 (other buffer)
         const int k0 = c * KC;
-        if (c + 1 < nchunks) prefetch(k0 + KC);  // in flight while chunk c is sampled
+        if (stage && c + 1 < nchunks) prefetch(k0 + KC);  // in flight while chunk c is sampled
 #pragma unroll
         for (int r = 0; r < KC; ++r) {
             // rows past the end of the march are staged as zeros and sampled with the last row's (valid) coordinates,

@@ -329,6 +329,63 @@ __global__ void permute3_kernel(const float *__restrict__ in, float *__restrict_
     }
 }
 
+
+// ---- halo staging for the z-slab exchange: up to 8 plane blocks (each contiguous in its own array) <-> ONE contiguous
+//      staging buffer, so a neighbour exchange is one message each way instead of one per array (RCCL point-to-point pays
+//      a fixed cost per op).  Blocks are copied as dwordx4 where source, destination and length allow it.
+constexpr int HALO_MAX_BLOCKS = 8;
+struct HaloBlocks {
+    const char *src[HALO_MAX_BLOCKS];
+    char *dst[HALO_MAX_BLOCKS];
+    size_t bytes[HALO_MAX_BLOCKS];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void halo_copy_kernel(HaloBlocks h)
+{
+    const int b = blockIdx.y;
+    const char *src = h.src[b];
+    char *dst = h.dst[b];
+    const size_t bytes = h.bytes[b];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool vec = (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0;
+    size_t done = 0;
+    if (vec) {
+        const size_t n16 = bytes >> 4;
+        for (size_t i = t0; i < n16; i += stride) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+        done = n16 << 4;
+    } else if ((((uintptr_t)src | (uintptr_t)dst) & 3u) == 0) {
+        const size_t n4 = bytes >> 2;
+        for (size_t i = t0; i < n4; i += stride) reinterpret_cast<unsigned *>(dst)[i] = reinterpret_cast<const unsigned *>(src)[i];
+        done = n4 << 2;
+    }
+    for (size_t i = done + t0; i < bytes; i += stride) dst[i] = src[i];
+}
+
+int halo_copy(const void *const *a, const void *b_contig, const size_t *bytes, int nblocks, bool pack, void *stream)
+{
+    TOMO_REQUIRE(nblocks >= 0 && nblocks <= HALO_MAX_BLOCKS, "a halo exchange packs at most %d blocks (got %d)", HALO_MAX_BLOCKS, nblocks);
+    if (nblocks == 0) return TOMO_OK;
+    TOMO_REQUIRE(a != nullptr && b_contig != nullptr && bytes != nullptr, "NULL halo block table");
+    HaloBlocks h;
+    h.n = nblocks;
+    size_t off = 0, largest = 0;
+    for (int i = 0; i < nblocks; ++i) {
+        TOMO_REQUIRE(a[i] != nullptr || bytes[i] == 0, "halo block %d is NULL", i);
+        char *stage = (char *)b_contig + off;
+        h.src[i] = pack ? (const char *)a[i] : stage;
+        h.dst[i] = pack ? stage : (char *)a[i];
+        h.bytes[i] = bytes[i];
+        off += (bytes[i] + 15) & ~(size_t)15;  // every block starts 16-byte aligned in the staging buffer
+        largest = std::max(largest, bytes[i]);
+    }
+    for (int i = nblocks; i < HALO_MAX_BLOCKS; ++i) { h.src[i] = nullptr; h.dst[i] = nullptr; h.bytes[i] = 0; }
+    const int gx = (int)std::min<size_t>(std::max<size_t>((largest / 16 + 255) / 256, 1), 512);
+    halo_copy_kernel<<<dim3(gx, nblocks), 256, 0, as_stream(stream)>>>(h);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
 }  // namespace
 
 extern "C" int tomo_momentum(const float *x, const float *xold, float *xt, float beta, size_t count, void *stream)
@@ -542,4 +599,21 @@ extern "C" int tomo_diag_stream(const float *const *in_dev, int nin, float *cons
     else diag_stream_kernel<1><<<grid, 256, 0, as_stream(stream)>>>(a);
     TOMO_LAUNCH_CHECK();
     return TOMO_OK;
+}
+
+extern "C" size_t tomo_halo_staging_bytes(const size_t *bytes, int nblocks)
+{
+    size_t off = 0;
+    for (int i = 0; bytes && i < nblocks; ++i) off += (bytes[i] + 15) & ~(size_t)15;
+    return off;
+}
+
+extern "C" int tomo_halo_pack(const void *const *src_dev, const size_t *bytes, int nblocks, void *staging_dev, void *stream)
+{
+    return halo_copy(src_dev, staging_dev, bytes, nblocks, true, stream);
+}
+
+extern "C" int tomo_halo_unpack(const void *staging_dev, void *const *dst_dev, const size_t *bytes, int nblocks, void *stream)
+{
+    return halo_copy((const void *const *)dst_dev, staging_dev, bytes, nblocks, false, stream);
 }

@@ -493,6 +493,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
             t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
             t.ring = ring; t.ring_scale = ring_scale;
             t.wpitch = wp;
+            t.probe = g_probe;
             t.nut = nut_w;
             t.bt = bt;
             t.ngroups = ceil_div(nc, FP_A);
@@ -570,6 +571,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
                 t.ring = ring; t.ring_scale = ring_scale;
                 t.wpitch = s.wbound[c];
+                t.probe = g_probe;
                 const int passes = ceil_div(t.wpitch, 256);           // 1..5 in the pipelined kernel
                 // (items per thread, double buffer) per pass count -- keep in step with FP_TILED_LAUNCH below
                 const int fp_m = passes <= 2 ? 8 : (passes == 5 ? 10 : 12);

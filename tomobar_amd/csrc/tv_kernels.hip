@@ -16,6 +16,7 @@
 //     HBM (12 B/voxel/iteration) and are evaluated once per voxel.  Variant 1: per-voxel form.
 // All arithmetic is float32 with the rounding sequence of oracle/tomo_oracle.c (explicit fmaf, -ffp-contract=off).
 #include "tomo_common.h"
+#include <algorithm>
 #include <utility>
 
 namespace {
@@ -459,6 +460,11 @@ extern "C" size_t tomo_roftv_scratch_bytes(int dx, int dy, int dz, int nd)
     return 2 * align_up((size_t)dx * dy * dz * sizeof(float), 256);
 }
 
+extern "C" int tomo_pdtv_iters_per_launch(int half)
+{
+    return g_variant_pdtv == 1 ? 1 : pd_iters_per_launch(g_variant_pdtv, half);
+}
+
 extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx, int dy, int dz, int nd,
                          float sigma, float tau, float lt, float theta, int iters, int methodTV, int nonneg,
                          int half, void *stream)
@@ -495,7 +501,8 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
     // 3D volumes run several iterations per launch (K = 3 or 2, see pd_multi_launch) while that many remain, then
     // single iterations; variant 1 keeps one iteration per launch (independent implementation)
     const int v = g_variant_pdtv;
-    const int kmax = (nd == 3 && v != 1) ? pd_iters_per_launch(v, half) : 1;
+    // a fused launch of k iterations marches k planes ahead of its output: volumes thinner than that take fewer per launch
+    const int kmax = (nd == 3 && v != 1) ? std::min(pd_iters_per_launch(v, half), dz) : 1;
     // cut `remaining` into launches of kmax / 2 / 1 iterations with as few single-iteration launches as possible
     // (4 = 2 + 2, 7 = 3 + 2 + 2: a single iteration costs 1.7x an iteration of a fused launch)
     auto step_of = [&](int remaining) {

@@ -26,7 +26,10 @@ def _sinc_ramp_filter(n: int, cutoff: float = 1.1) -> np.ndarray:
     w = np.linspace(-np.pi, np.pi - (2 * np.pi) / n, n, dtype="float32")
     rd = (cutoff * w) / 2.0
     rn2 = np.sin(rd)
-    gain = (float(np.dot(rn2, rd)) / float(np.dot(rd, rd))) ** 2   # dot(rn2, pinv(row vector rd)) = <rn2, rd>/||rd||^2
+    # dot(rn2, pinv(row vector rd)) = <rn2, rd> / ||rd||^2, in float64 like the reference (its rd_c is a float64 array
+    # holding the float32 values, methodsDIR.py:273-276,309-312), so the response itself is float64 too
+    rd64, rn64 = rd.astype(np.float64), rn2.astype(np.float64)
+    gain = (np.dot(rn64, rd64) / np.dot(rd64, rd64)) ** 2
     return scipy.fft.fftshift(np.abs(2.0 / cutoff * rn2) * gain)
 
 

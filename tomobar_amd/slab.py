@@ -22,6 +22,7 @@ the oracle's single-iteration functions.
 from __future__ import annotations
 
 import ctypes as C
+import time
 from typing import Callable, List, Optional
 
 import numpy as np
@@ -74,7 +75,11 @@ class SlabComm:
         self.has_hi = self.rank < self.world - 1
         self.backend = dist.get_backend(group) if dist.is_initialized() else "gloo"
         self.staged = self.backend != "nccl"   # tensors handed to the backend must live on the host
-        self._validated = set()
+        self._stage_bufs = {}
+        self._events = []
+        self._wait_stream_ms = 0.0
+        self.timing = False   # bench.py switches the HIP-event timing of the waits on
+        self.stats = {"exchanges": 0, "messages": 0, "bytes": 0, "post_host_ms": 0.0, "wait_host_ms": 0.0}
 
     def _scalar_device(self):
         return None if self.staged else self.device
@@ -100,78 +105,175 @@ class SlabComm:
         self.dist.barrier(group=self.group)
 
     def validate_slabs(self, nz_local: int, min_slices: int = 2):
-        """Collective check (once per local slab height): every rank learns every slab's height and ALL ranks raise
-        together if one of them is too short for the ghost planes -- never a lone rank, which would strand its
-        neighbours inside a send/recv."""
-        key = (int(nz_local), int(min_slices))
-        if self.world == 1 or key in self._validated:
+        """Collective check, run on EVERY call by EVERY rank (one int per rank): every rank learns every slab's height
+        and ALL ranks raise together if one of them is too short for the ghost planes -- never a lone rank, which would
+        strand its neighbours inside a send/recv.  (No per-rank cache: ranks whose local heights differ -- 9 slices over
+        2 ranks is 5 + 4 -- would disagree about whether to join the all-gather.)"""
+        if self.world == 1:
             return
         heights = self.allgather_int(nz_local)
-        self._validated.add(key)
         short = [r for r, h in enumerate(heights) if h < min_slices]
         if short:
             raise ValueError(f"z-slabs of ranks {short} hold fewer than {min_slices} slices (heights {heights}): "
-                             "3D TV needs two-plane ghosts; use fewer ranks or balance the split with slab_bounds()")
+                             f"3D TV needs {min_slices}-plane ghosts; use fewer ranks or balance the split with slab_bounds()")
 
     # ---- halo exchange
+    def _staging(self, key, nbytes, device):
+        buf = self._stage_bufs.get(key)
+        if buf is None or buf.numel() < nbytes or buf.device != device:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._stage_bufs[key] = buf
+        return buf[:int(nbytes)]
+
     def _post(self, send_down, recv_down, send_up, recv_up):
-        """Post every send / receive of one exchange as ONE batch; returns completion handles."""
+        """One exchange = at most ONE send and ONE receive per neighbour: the blocks of a direction (U, P1, P2, P3 planes,
+        each contiguous in its own array) are packed into one staging buffer (tomo_halo_pack) and scattered back on
+        arrival (tomo_halo_unpack).  Returns a handle whose wait() completes the transfers and the scatter."""
+        t_host = time.perf_counter()
         P2POp = self.dist.P2POp
-        plan = []
-        if self.has_lo:
-            plan += [(self.dist.isend, t, self.rank - 1) for t in send_down]
-            plan += [(self.dist.irecv, t, self.rank - 1) for t in recv_down]
-        if self.has_hi:
-            plan += [(self.dist.isend, t, self.rank + 1) for t in send_up]
-            plan += [(self.dist.irecv, t, self.rank + 1) for t in recv_up]
+        plan, unpack = [], []
+        for name, tensors, peer, fn in (("sd", send_down, self.rank - 1, self.dist.isend),
+                                        ("rd", recv_down, self.rank - 1, self.dist.irecv),
+                                        ("su", send_up, self.rank + 1, self.dist.isend),
+                                        ("ru", recv_up, self.rank + 1, self.dist.irecv)):
+            if not tensors or peer < 0 or peer >= self.world:
+                continue
+            for t in tensors:
+                if not t.is_contiguous():
+                    raise ValueError("halo blocks must be contiguous plane ranges")
+            nbytes = [t.numel() * t.element_size() for t in tensors]
+            stage = self._staging(name, _halo_staging_bytes(nbytes), tensors[0].device)
+            if fn is self.dist.isend:
+                _hip_halo_pack(tensors, nbytes, stage)
+            else:
+                unpack.append((stage, tensors, nbytes))
+            plan.append((fn, stage, peer))
+            self.stats["messages"] += 1
+            self.stats["bytes"] += int(sum(nbytes)) if fn is self.dist.isend else 0
         if not plan:
-            return []
+            return _Exchange(self, [], [], None)
         if not (self.staged and any(t.is_cuda for _, t, _ in plan)):
-            return list(self.dist.batch_isend_irecv([P2POp(fn, t, peer, self.group) for fn, t, peer in plan]))
-        # host staging: the device->host copies of the planes to send are synchronous with the current stream, i.e.
-        # ordered after the kernels that produced them
-        ops, hosts = [], []
-        for fn, t, peer in plan:
-            h = t.cpu() if fn is self.dist.isend else torch.empty(t.shape, dtype=t.dtype)
-            hosts.append((h, t if fn is self.dist.irecv else None))
-            ops.append(P2POp(fn, h, peer, self.group))
-        reqs = self.dist.batch_isend_irecv(ops)
-        return [_StagedRequest(r, h, d) for r, (h, d) in zip(reqs, hosts)]
+            reqs = list(self.dist.batch_isend_irecv([P2POp(fn, t, peer, self.group) for fn, t, peer in plan]))
+        else:
+            # host staging (gloo moving device tensors): the device->host copy of a packed buffer is synchronous with the
+            # current stream, i.e. ordered after the pack kernel and the kernels that produced the planes
+            ops, hosts = [], []
+            for fn, t, peer in plan:
+                h = t.cpu() if fn is self.dist.isend else torch.empty(t.shape, dtype=t.dtype)
+                hosts.append((h, t if fn is self.dist.irecv else None))
+                ops.append(P2POp(fn, h, peer, self.group))
+            reqs = [_StagedRequest(r, h, d) for r, (h, d) in zip(self.dist.batch_isend_irecv(ops), hosts)]
+        self.stats["exchanges"] += 1
+        self.stats["post_host_ms"] += (time.perf_counter() - t_host) * 1e3
+        return _Exchange(self, reqs, unpack, plan[0][1].device)
 
     def exchange(self, send_down: List[torch.Tensor], recv_down: List[torch.Tensor],
                  send_up: List[torch.Tensor], recv_up: List[torch.Tensor]):
-        """send_down/recv_down talk to rank-1, send_up/recv_up to rank+1.  All planes are contiguous views; the k-th
+        """send_down/recv_down talk to rank-1, send_up/recv_up to rank+1.  All blocks are contiguous views; the k-th
         tensor sent up by rank r lands in the k-th tensor of rank r+1's recv_down (and likewise downwards)."""
-        for req in self._post(send_down, recv_down, send_up, recv_up):
-            req.wait()
+        self._post(send_down, recv_down, send_up, recv_up).wait()
 
     def exchange_start(self, send_down, recv_down, send_up, recv_up):
-        """Asynchronous form of `exchange`: returns the requests.  With the nccl (RCCL) backend the transfers are ordered
-        after the work already queued on the current stream and run on RCCL's own stream, so kernels launched after this
-        call overlap with them; `exchange_wait` makes the current stream wait for their completion."""
+        """Asynchronous form of `exchange`: returns the handle.  With the nccl (RCCL) backend the transfers are ordered
+        after the work already queued on the current stream (the pack kernels included) and run on RCCL's own stream, so
+        kernels launched after this call overlap with them; `exchange_wait` makes the current stream wait for their
+        completion and scatters the received planes."""
         return self._post(send_down, recv_down, send_up, recv_up)
 
     @staticmethod
-    def exchange_wait(reqs):
-        for req in reqs:
+    def exchange_wait(handle):
+        handle.wait()
+
+    def timing_summary(self) -> dict:
+        """Per-rank exchange statistics since construction (bench.py prints them): messages, payload bytes sent, host time
+        spent posting (``post_host_ms``) and blocked in wait (``wait_host_ms``), and -- for device tensors -- the time the
+        compute stream stood still between the start of a wait and the end of the scatter (``wait_stream_ms``, HIP events
+        on the current stream; with RCCL this is what the exchange costs the kernels, the rest is overlapped)."""
+        out = dict(self.stats)
+        if self._events:
+            torch.cuda.synchronize()
+            self._wait_stream_ms += float(sum(a.elapsed_time(b) for a, b in self._events))
+            self._events = []
+        if self._wait_stream_ms or self.timing:
+            out["wait_stream_ms"] = self._wait_stream_ms
+        out["backend"] = self.backend
+        return out
+
+
+class _Exchange:
+    """Handle of one packed halo exchange: wait() completes the requests and scatters what arrived."""
+
+    def __init__(self, comm, reqs, unpack, device):
+        self.comm, self.reqs, self.unpack, self.device = comm, reqs, unpack, device
+
+    def wait(self):
+        comm = self.comm
+        t_host = time.perf_counter()
+        on_gpu = self.device is not None and self.device.type == "cuda" and comm.timing
+        if on_gpu:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+        for req in self.reqs:
             req.wait()
+        for stage, tensors, nbytes in self.unpack:
+            _hip_halo_unpack(stage, tensors, nbytes)
+        if on_gpu:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream(self.device))
+            comm._events.append((e0, e1))
+        comm.stats["wait_host_ms"] += (time.perf_counter() - t_host) * 1e3
+        self.reqs, self.unpack = [], []
+
+
+def _halo_staging_bytes(nbytes):
+    """tomo_halo_staging_bytes: every block starts 16-byte aligned in the staging buffer."""
+    return sum((int(b) + 15) // 16 * 16 for b in nbytes)
+
+
+def _hip_halo_pack(tensors, nbytes, staging):
+    from . import _lib as L
+    from . import ops
+    n = len(tensors)
+    src = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    nb = (C.c_size_t * n)(*[int(b) for b in nbytes])
+    with torch.cuda.device(staging.device):
+        L.check(L.lib().tomo_halo_pack(src, nb, n, ops.ptr(staging), ops.stream_ptr(staging)))
+
+
+def _hip_halo_unpack(staging, tensors, nbytes):
+    from . import _lib as L
+    from . import ops
+    n = len(tensors)
+    dst = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    nb = (C.c_size_t * n)(*[int(b) for b in nbytes])
+    with torch.cuda.device(staging.device):
+        L.check(L.lib().tomo_halo_unpack(ops.ptr(staging), dst, nb, n, ops.stream_ptr(staging)))
+
+
+def _hip_pd_kmax(half: bool) -> int:
+    """PD_TV iterations per fused launch, asked of the library (csrc/tv_kernels.hip: pd_iters_per_launch)."""
+    from . import _lib as L
+    return int(L.lib().tomo_pdtv_iters_per_launch(int(bool(half))))
 
 
 # ------------------------------------------------------------------------------------------------ PD_TV on a slab
 GHOST = 3  # ghost planes below / above an interior boundary: as deep as the longest fused launch (3 iterations)
 
 
-def pd_launch_plan(iterations: int, half: bool):
-    """How tomo_pdtv cuts `iterations` into fused launches (csrc/tv_kernels.hip: step_of): 3 iterations per launch for
-    float32 duals, 2 for binary16 duals, as few single-iteration launches as possible (4 = 2 + 2).  The slab driver uses
-    the same plan, so a slab run is launch for launch the whole-volume run."""
-    kmax = 2 if half else 3
+def pd_launch_plan(iterations: int, half: bool, kmax: Optional[int] = None):
+    """How tomo_pdtv cuts `iterations` into fused launches (csrc/tv_kernels.hip: step_of): `kmax` iterations per launch
+    (asked of the library: 3 for float32 duals, 2 for binary16 duals in the shipped build), as few single-iteration
+    launches as possible (4 = 2 + 2).  The slab driver uses the same plan, so a slab run is launch for launch the
+    whole-volume run."""
+    if kmax is None:
+        kmax = _hip_pd_kmax(half)
+    kmax = max(1, min(int(kmax), GHOST))
     plan, rem = [], int(iterations)
     while rem > 0:
         if kmax >= 3 and rem >= 3 and rem != 4:
             k = 3
         else:
-            k = 2 if rem >= 2 else 1
+            k = 2 if (rem >= 2 and kmax >= 2) else 1
         plan.append(k)
         rem -= k
     return plan
