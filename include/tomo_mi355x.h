@@ -317,9 +317,11 @@ int tomo_fourier_inv(int device, const float *data_dev, float *out_dev, int nz, 
                      int m, float mu, int center_size, void *stream);
 
 /* kernel-variant selector (per calling host thread): name in {"bp","fp","pdtv","roftv"}; variant 0 = shipped default.
- * The ones a user may care about: "pdtv" / "roftv" 2 = the builds that reproduce the reference kernels' rounding
- * sequence bit for bit (IEEE sqrt / divide; the shipped builds use v_rsq / hoisted reciprocals for float32 duals and stay
- * within 1e-5 of them), 3 = relaxed arithmetic for binary16 duals as well.  Everything else is A/B measurement. */
+ * The ones a user may care about: "pdtv" 2 = the build that reproduces the reference kernels' rounding sequence bit for
+ * bit (IEEE sqrt / divide; the shipped float32-dual build uses v_rsq / a hoisted reciprocal and stays within 1e-5 of it),
+ * 3 = relaxed arithmetic for binary16 duals as well.  "roftv" 0 already reproduces the reference's roundings (FMA-corrected
+ * sqrt / divide); 3 = relaxed arithmetic (30 % faster, can leave the 1e-5 band on noise-dominated data).  Everything else
+ * ("probe" included) is A/B measurement. */
 int tomo_set_variant(const char *kernel, int variant);
 
 /* In-library kernel timing for bench.py's roofline object: while enabled, every launch group of a kernel class

@@ -19,8 +19,6 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 fp = C.POINTER(C.c_float)
 TOL = 1e-5
-# the product may sit this many reference-build spreads from the nearer reference build (measured: profiles/r3_rof_noise_reference_spread.txt)
-ROF_SPREAD_FACTOR = 1.0
 
 
 def rel(a, b):
@@ -118,14 +116,15 @@ ROF_NOISE_SHAPES = [(6, 9, 13), (1, 20, 17), (12, 1, 70), (10, 11, 1), (8, 8, 8)
 
 
 @pytest.mark.default_arithmetic
-def test_shipped_roftv_on_noise_is_within_the_reference_builds_own_spread(oracle):
-    """VERDICT round 2, weak #2.  The shipped ROF_TV (float32 sum + v_rsq_f32) leaves the 1e-5 band on noise-dominated
-    inputs after 60 iterations -- and so does the REFERENCE against itself: its kernel source built with and without FMA
-    contraction (NVRTC's default is --fmad=true; oracle/_ref/libref_tv_fma.so vs libref_tv.so, both made from
-    rudin_osher_fatemi_total_variation.cu) differs by up to 2.4e-5 on exactly these inputs, because D = a / sqrt(a^2 +
-    m + 1e-8) has a gain of ~1e4 where all differences are at the 1e-4 level.  The product's bound on such inputs is
-    therefore the measured spread of the two reference builds on the SAME input (never a round number), and the plain
-    1e-5 wherever the reference agrees with itself to 1e-5."""
+def test_shipped_roftv_on_noise_against_both_reference_builds(oracle):
+    """VERDICT round 2, weak #2.  On noise-dominated inputs ROF_TV is ill-conditioned (D = a / sqrt(a^2 + m + 1e-8) has a
+    gain of ~1e4 where all differences are ~1e-4): after 60 iterations the REFERENCE differs from itself by up to 2.4e-5
+    between its two builds -- rudin_osher_fatemi_total_variation.cu with and without FMA contraction (NVRTC's default is
+    --fmad=true; oracle/_ref/libref_tv_fma.so vs libref_tv.so) -- and the former relaxed product build drifted to
+    2.5e-5 .. 4.5e-5 there.  The shipped build now reproduces the roundings of the contracted reference build exactly:
+    bit-identical to libref_tv_fma.so's output (float32 D fields) on every one of these inputs, hence exactly as far
+    from the uncontracted build as the reference itself is.  The table is written to gpurun_out/ (committed under
+    profiles/r3_rof_noise_reference_spread.txt)."""
     from tomobar_amd import ops
     from tomobar_amd.regularisersCuPy import ROF_TV_cupy
     Loff, Lfma = load("libref_tv.so"), load("libref_tv_fma.so")
@@ -137,16 +136,18 @@ def test_shipped_roftv_on_noise_is_within_the_reference_builds_own_spread(oracle
         for half in (0, 1):
             r_off = ref_rof(Loff, oracle, x, 0.05, 60, 0.005, half)
             r_fma = ref_rof(Lfma, oracle, x, 0.05, 60, 0.005, half)
+            want = oracle.rof_tv(x, 0.05, 60, 0.005, bool(half))
             spread = rel(r_fma, r_off)
             got = ROF_TV_cupy(torch.from_numpy(x).cuda(), 0.05, 60, 0.005, 0, bool(half))
             torch.cuda.synchronize()
             g = got.cpu().numpy()
             e_off, e_fma = rel(g, r_off), rel(g, r_fma)
-            err = min(e_off, e_fma)
-            bound = max(TOL, ROF_SPREAD_FACTOR * spread)
+            same = np.array_equal(g, want)
             lines.append(f"{str(shape):16s} half={half} reference fma-vs-off {spread:.2e}  product-vs-off {e_off:.2e} "
-                         f"product-vs-fma {e_fma:.2e}  bound {bound:.2e}")
-            if err > bound:
+                         f"product-vs-fma {e_fma:.2e}  product == oracle: {same}")
+            # the oracle restates the contracted build: product == oracle bit for bit; against the reference binaries the
+            # product is never further from a build than the other build is (float32: identical to the fma build)
+            if not same or e_fma > max(TOL, spread) or e_off > max(TOL, 1.01 * spread + 1e-7):
                 bad.append(lines[-1])
     text = "\n".join(lines)
     print(text)

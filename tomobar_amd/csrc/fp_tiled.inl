@@ -103,36 +103,42 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
     __syncthreads();
 
     const size_t zstride = (size_t)n * n;
-    // slices beyond nz read slice nz-1 (valid memory) and are zeroed by the select below
+    // slices beyond nz read slice nz-1 (valid memory) through a zero-length descriptor, i.e. as zeros
     const float *p0 = a.src + (size_t)z0 * zstride;
     const float *p1 = a.src + (size_t)min(z0 + 1, a.nz - 1) * zstride;
     const float *p2 = a.src + (size_t)min(z0 + 2, a.nz - 1) * zstride;
     const float *p3 = a.src + (size_t)min(z0 + 3, a.nz - 1) * zstride;
-    const unsigned k1 = z0 + 1 < a.nz ? 0xffffffffu : 0u, k2 = z0 + 2 < a.nz ? 0xffffffffu : 0u, k3 = z0 + 3 < a.nz ? 0xffffffffu : 0u;
+    const int rowbytes = n * 4;
+    const int nb1 = z0 + 1 < a.nz ? rowbytes : 0, nb2 = z0 + 2 < a.nz ? rowbytes : 0, nb3 = z0 + 3 < a.nz ? rowbytes : 0;
 
     float4 pre[M];
-    // branch-free gather of the chunk starting at row k0 into registers: pre[r * PASSES + p] <- (row k0+r, column tid + BT p).
-    // Invalid items (outside the window / volume / march) load a clamped address and are zeroed with a bit mask.
+    // Gather of the chunk starting at row k0 into registers: pre[r * PASSES + p] <- (row k0+r, column tid + BT p).
+    // One buffer descriptor per (row, slice) -- base = the row, num_records = n floats, built by scalar instructions --
+    // lets the hardware's range check do what used to be 12 VALU per item: a column left of the volume (negative offset =
+    // huge unsigned), right of it, beyond the window (offset forced out of range) or a row past the march loads 0.
     auto prefetch = [&](int k0) {
 #pragma unroll
         for (int r = 0; r < KC; ++r) {
             const int k = min(k0 + r, n - 1);
-            const int lo = win_lo[k], wid = (k0 + r < n) ? win_wid[k] : 0;
-            const unsigned rowoff = (unsigned)k * (unsigned)n;
+            const int lo4 = __builtin_amdgcn_readfirstlane(win_lo[k]) * 4;
+            const int wid = (k0 + r < n) ? __builtin_amdgcn_readfirstlane(win_wid[k]) : 0;
+            const size_t rowoff = (size_t)k * (size_t)n;
+            const __amdgpu_buffer_rsrc_t d0 = __builtin_amdgcn_make_buffer_rsrc((void *)(p0 + rowoff), 0, rowbytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t d1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p1 + rowoff), 0, nb1, 0x00020000);
+            const __amdgpu_buffer_rsrc_t d2 = __builtin_amdgcn_make_buffer_rsrc((void *)(p2 + rowoff), 0, nb2, 0x00020000);
+            const __amdgpu_buffer_rsrc_t d3 = __builtin_amdgcn_make_buffer_rsrc((void *)(p3 + rowoff), 0, nb3, 0x00020000);
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
                 const int j = tid + bt * p;
-                const int x = lo + j;
-                const unsigned mk = (j < wid && x >= 0 && x < n) ? 0xffffffffu : 0u;
-                const unsigned off = rowoff + (unsigned)min(max(x, 0), n - 1);
+                const int off = (j < wid) ? (j << 2) + lo4 : (int)0x80000000;
                 float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 // a wave whose 64 columns all lie beyond the window skips the pass (wave-uniform: scalar branch); with
                 // BT = 1024 the second pass of a 1030-column row keeps one wave of sixteen busy
-                if (p == 0 || __builtin_amdgcn_readfirstlane(j - (tid & 63)) < __builtin_amdgcn_readfirstlane(wid)) {
-                    v.x = __uint_as_float(__float_as_uint(p0[off]) & mk);
-                    v.y = __uint_as_float(__float_as_uint(p1[off]) & (mk & k1));
-                    v.z = __uint_as_float(__float_as_uint(p2[off]) & (mk & k2));
-                    v.w = __uint_as_float(__float_as_uint(p3[off]) & (mk & k3));
+                if (p == 0 || __builtin_amdgcn_readfirstlane(j - (tid & 63)) < wid) {
+                    v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d0, off, 0, 0));
+                    v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d1, off, 0, 0));
+                    v.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d2, off, 0, 0));
+                    v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d3, off, 0, 0));
                 }
                 pre[r * PASSES + p] = v;
             }
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
     for (int c = 0; c < nchunks; ++c) {
         float4 *tile = (c & 1) ? tile1 : tile0;
         if (!DB) __syncthreads();  // every wave is past the sampling of chunk c-1 (same buffer)
-        if (stage) {
+        if (stage && !(a.probe & 32)) {
 #pragma unroll
             for (int r = 0; r < KC; ++r)
 #pragma unroll
@@ -158,6 +164,9 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
                     if (p == 0 || __builtin_amdgcn_readfirstlane(j - (tid & 63)) < a.wpitch)
                         if (j < a.wpitch) tile[r * a.wpitch + j] = pre[r * PASSES + p];
                 }
+        } else if (stage) {  // measurement: the global loads are kept alive, the LDS writes are skipped
+#pragma unroll
+            for (int i = 0; i < M; ++i) asm volatile("" ::"v"(pre[i].x), "v"(pre[i].y), "v"(pre[i].z), "v"(pre[i].w));
         }
         __syncthreads();  // chunk c staged; every wave is past the sampling of chunk c-1 (other buffer)
         const int k0 = c * KC;

@@ -9,7 +9,7 @@
 // z = 0 plane, whose backward difference reflects to D3 of plane 1 (:228-235): it is evaluated in the first step.
 struct RofD { float d1, d2, d3; };
 
-template <int ND, bool HALF, bool FAST>
+template <int ND, bool HALF, int FAST>
 __device__ __forceinline__ RofD rof_eval(float u, float u_i1, float u_i2, float u_j1, float u_j2, float u_k1, float u_k2)
 {
     // reference naming: "x" differences run along j (rows), "y" along i (lanes)  (rudin_osher...cu:183-188)
@@ -18,8 +18,26 @@ __device__ __forceinline__ RofD rof_eval(float u, float u_i1, float u_i2, float 
     const float dxm = rof_mm(nx0, nx1), dym = rof_mm(ny0, ny1);
     RofD d;
     // FAST: float32 sum + v_rsq_f32 instead of the reference's double-precision sum, IEEE sqrt and IEEE divide
+    // FAST = 1 (relaxed): float32 sum + v_rsq_f32;  0: the compiler's IEEE sqrt + divide (denormal-safe expansions);
+    // 3: the reference's roundings reproduced with fused-multiply-add correction steps (Markstein): the double-precision
+    //    sum as is, sqrt = v_rsq + two coupled Newton steps + one exact-residual correction, quotient = v_rcp + one Newton
+    //    step + one exact-residual correction -- correctly rounded for the operands that occur here (x >= 1e-8, normal);
+    // 2: 3 without the final residual corrections (<= 1 ulp, not always correctly rounded)
     auto nrm = [](float nom, float d1, float d2, float d3) {
-        return FAST ? nom * __builtin_amdgcn_rsqf(((d1 + d2) + d3) + 1.0e-8f) : rof_norm(nom, d1, d2, d3);
+        if (FAST == 1) return nom * __builtin_amdgcn_rsqf(((d1 + d2) + d3) + 1.0e-8f);
+        if (FAST == 0) return rof_norm(nom, d1, d2, d3);
+        const float x = (float)((double)((d1 + d2) + d3) + 1.0e-8);
+        const float r = __builtin_amdgcn_rsqf(x);
+        float q = x * r, h = 0.5f * r;
+        const float e = fmaf(-h, q, 0.5f);
+        q = fmaf(q, e, q);
+        h = fmaf(h, e, h);
+        if (FAST == 3) q = fmaf(fmaf(-q, q, x), h, q);   // correctly rounded sqrt(x)
+        float y = __builtin_amdgcn_rcpf(q);
+        y = fmaf(fmaf(-q, y, 1.0f), y, y);
+        float z = nom * y;
+        if (FAST == 3) z = fmaf(fmaf(-q, z, nom), y, z);  // correctly rounded nom / q
+        return z;
     };
     if (ND == 3) {
         const float nz1 = u_k1 - u, nz0 = u - u_k2;
@@ -38,7 +56,7 @@ __device__ __forceinline__ RofD rof_eval(float u, float u_i1, float u_i2, float 
     return d;
 }
 
-template <int ND, bool HALF, bool FAST, int RY, int WX, int WY>
+template <int ND, bool HALF, int FAST, int RY, int WX, int WY>
 __global__ __launch_bounds__(64 * WX * WY) void rof_zmarch_kernel(RofArgs a, int gx, int gy, int tiles_per_xcd, int zchunk)
 {
     // every XCD owns one contiguous eighth of the row-major (yb, xb) tile list: a band of rows whose halos meet in that
@@ -158,7 +176,7 @@ __global__ __launch_bounds__(64 * WX * WY) void rof_zmarch_kernel(RofArgs a, int
     }
 }
 
-template <int ND, bool HALF, bool FAST, int RY, int WX, int WY>
+template <int ND, bool HALF, int FAST, int RY, int WX, int WY>
 static int rof_zmarch_launch(const RofArgs &a, hipStream_t st)
 {
     const int nout = a.out_end - a.out_begin;

@@ -44,10 +44,19 @@ template <> struct DualIO<float> {
     static __device__ __forceinline__ void st(float *p, size_t i, float v) { p[i] = v; }
     static __device__ __forceinline__ float rt(float v) { return v; }
 };
+// binary16 rounding of a float32 RESULT: the reference rounds twice (the operation to float32, then the store / conversion to
+// binary16).  hipcc folds "fmaf(...) then float->half" into v_fma_mixlo_f16, which rounds the exact fused result ONCE --
+// a different value in the double-rounding cases (found in round 3: ROF_TV with binary16 D fields, one voxel in 512 after
+// 20 iterations).  The empty asm makes the float32 value opaque, so the conversion always starts from the rounded float.
+__device__ __forceinline__ __half f32_to_half_twice_rounded(float v)
+{
+    asm volatile("" : "+v"(v));
+    return __float2half_rn(v);
+}
 template <> struct DualIO<__half> {
     static __device__ __forceinline__ float ld(const __half *p, size_t i) { return __half2float(p[i]); }
-    static __device__ __forceinline__ void st(__half *p, size_t i, float v) { p[i] = __float2half_rn(v); }
-    static __device__ __forceinline__ float rt(float v) { return __half2float(__float2half_rn(v)); }
+    static __device__ __forceinline__ void st(__half *p, size_t i, float v) { p[i] = f32_to_half_twice_rounded(v); }
+    static __device__ __forceinline__ float rt(float v) { return __half2float(f32_to_half_twice_rounded(v)); }
 };
 
 // dual ascent + projection onto the unit ball (isotropic) / unit cube (anisotropic)
@@ -82,7 +91,7 @@ struct PlaneIO {
     }
     __device__ __forceinline__ void std_(__half *plane, unsigned boff, float v) const
     {
-        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, __float2half_rn(v)), rs(plane, bytes >> 1),
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, f32_to_half_twice_rounded(v)), rs(plane, bytes >> 1),
                                               (int)(boff >> 1), 0, 0);
     }
 };
@@ -398,14 +407,20 @@ __global__ __launch_bounds__(256) void rof_pervoxel_kernel(RofArgs a)
 
 #include "rof_zmarch.inl"
 
-// variant 0: z-march with relaxed arithmetic (default); 2: z-march, the reference's exact rounding sequence;
-// 1: per-voxel kernel (independent implementation)
+// variant 0 (shipped, float32 and binary16 D fields): the reference's rounding sequence reproduced with FMA correction
+//            steps (rof_eval FAST = 3): bit-identical to the oracle, 4.2 ms per 1024^3 iteration;
+//         2: the same roundings through the compiler's IEEE sqrt / divide expansions (independent check, 4.8 ms);
+//         3: relaxed arithmetic (float32 sum + v_rsq_f32, 2.95 ms) -- measurement only: the D normalisation has a gain of
+//            ~1e4 on noise-dominated data, where one-ulp differences grow to 2.5e-5 .. 4.5e-5 after 60 iterations
+//            (profiles/r3_rof_variants.txt), beyond the 1e-5 parity bar;  4: refined v_rsq / v_rcp (no better than 3);
+//         1: per-voxel kernel (independent implementation)
 template <int ND, bool HALF>
 int rof_zmarch_dispatch(const RofArgs &a, int variant, hipStream_t st)
 {
-    // binary16 D fields keep the exact arithmetic by default (see pd_multi_launch); variant 3 relaxes them too
-    int rc = (variant == 2 || (HALF && variant != 3)) ? rof_zmarch_launch<ND, HALF, false, 8, 2, 2>(a, st)
-                                                      : rof_zmarch_launch<ND, HALF, true, 8, 2, 2>(a, st);
+    int rc = variant == 4 ? rof_zmarch_launch<ND, HALF, 2, 8, 2, 2>(a, st)
+             : variant == 3 ? rof_zmarch_launch<ND, HALF, 1, 8, 2, 2>(a, st)
+             : variant == 2 ? rof_zmarch_launch<ND, HALF, 0, 8, 2, 2>(a, st)
+                            : rof_zmarch_launch<ND, HALF, 3, 8, 2, 2>(a, st);
     if (rc != TOMO_OK) return rc;
     TOMO_LAUNCH_CHECK();
     return TOMO_OK;

@@ -1,5 +1,5 @@
 """What the staging (global loads + LDS writes of the volume rows) costs the forward projector: the probe switch skips it
-(the sampling loop, barriers and epilogue are unchanged; results are garbage).  usage: python tools/fp_stage_probe.py [N] [NZ] [NA]"""
+(the sampling loop, barriers and epilogue are unchanged; results are garbage); 32 skips only the LDS writes.  usage: python tools/fp_stage_probe.py [N] [NZ] [NA]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import statistics
@@ -17,7 +17,7 @@ sub = 3 if OS > 1 else None
 out = torch.empty(H.sino_shape(sub), device="cuda")
 res = {}
 for rnd in range(4):
-    for probe in (0, 16):
+    for probe in (0, 32, 16):
         ops.set_variant("probe", probe)
         H.forward(vol, sub, out=out)
         torch.cuda.synchronize()
