@@ -36,7 +36,7 @@ out["pdtv"] = {
     "note": "traffic_bytes = (first + last + 8 x middle) / 10, the per-launch mean of the bench's 30-iteration prox"}
 for name, what, keys, wl in (
         ("pdtv_half", "pdtv0h", ["x2_kernel"], "1024^3 f16 duals, 2 iterations/launch (pd_zmarch_x2, exact arithmetic); middle launch"),
-        ("roftv", "roftv", ["rof_"], "1024^3, 1 iteration/launch (rof_zmarch, relaxed arithmetic); later launches"),
+        ("roftv", "roftv", ["rof_"], "1024^3, 1 iteration/launch (rof_zmarch, shipped build: FMA-corrected reference roundings); later launches"),
         ("bp", "bp0", ["bp_brick"], "1024^3, 75 angles (one subset), bp_brick_kernel"),
         ("fp", "fp", ["fp_tiled", "transpose"], "1024^3, 75 angles (one subset): 2 launches of fp_tiled_kernel<...,1024> + the in-plane transpose")):
     fs = ws = 0.0
