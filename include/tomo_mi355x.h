@@ -260,7 +260,7 @@ int tomo_pdtv_pair_slab_range(int device, const float *in_dev, const float *u_in
 /* K iterations (k = 2 or 3) in one pass on a slab whose arrays carry lo_planes / hi_planes in {0, k..3} ghost planes.
  * Ghost planes that must be valid on entry: U and P1..3 k planes below, U k planes and P1..3 k-1 planes above, Input
  * k-1 planes either side.  Result = k applications of tomo_pdtv_iter_slab with ghost refreshes in between, bit for bit.
- * (Which k a run uses is the host's choice: tomobar_amd/slab.py mirrors tomo_pdtv -- 3 for float32 duals, 2 for binary16.) */
+ * (Which k a run uses is the host's choice: tomobar_amd/slab.py asks tomo_pdtv_iters_per_launch -- 3 for both dual types in the shipped build.) */
 int tomo_pdtv_multi_slab_range(int device, const float *in_dev, const float *u_in_dev, float *u_out_dev,
                                const void *p_in_dev[3], void *p_out_dev[3], int dx, int dy, int nz_local,
                                int lo_planes, int hi_planes, int z_begin, int z_end, int k, float sigma, float tau,

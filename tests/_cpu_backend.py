@@ -157,7 +157,7 @@ def install(monkeypatch=None):
             off += (nb + 15) // 16 * 16
 
     sets = [(SL, "_hip_halo_pack", halo_pack), (SL, "_hip_halo_unpack", halo_unpack),
-            (SL, "_hip_pd_kmax", lambda half: 2 if half else 3), (IR, "ops", ops), (IR, "HipTools3D", OracleTools3D), (REG, "ops", ops), (DI, "ops", ops), (ST, "ops", ops),
+            (SL, "_hip_pd_kmax", lambda half: 3), (IR, "ops", ops), (IR, "HipTools3D", OracleTools3D), (REG, "ops", ops), (DI, "ops", ops), (ST, "ops", ops),
             (SL, "_hip_pd_pair", O.pd_pair_slab), (SL, "_hip_pd_step", O.pd_step_slab), (SL, "_hip_rof_step", O.rof_step_slab)]
     for mod, name, val in sets:
         if monkeypatch is not None:

@@ -186,7 +186,7 @@ def test_fused_residual_and_gradient_steps(oracle, ops):
 
 # ------------------------------------------------------------------------------------------ TV operators
 TV_SHAPES = [(6, 9, 13), (1, 20, 17), (12, 1, 70), (10, 11, 1), (8, 8, 8), (3, 5, 131), (24, 19), (20, 70, 150)]
-PD_EXACT_VARIANTS = [2, 1, 21]   # bit-identical to the oracle; 0 (default), 3: relaxed arithmetic (tolerance)
+PD_EXACT_VARIANTS = [2, 1, 21, 22]   # bit-identical to the oracle (22: FMA-corrected roundings); 0 (default f32), 3: relaxed arithmetic (tolerance)
 
 
 @pytest.mark.parametrize("shape", TV_SHAPES)
@@ -411,9 +411,10 @@ def test_tv_random_shapes(oracle, ops, seed):
     want_pd = oracle.pd_tv(x, lam, iters, mtv, nn, 8.0, half)
     got = host(PD_TV_cupy(dev(x), lam, iters, mtv, nn, 8.0, 0, half))
     assert np.array_equal(got, want_pd), ("pd", shape, iters, half, mtv, nn, np.abs(got - want_pd).max())
-    ops.set_variant("pdtv", 21)  # exact arithmetic on the SHIPPED three-iteration tiling (8 rows per lane, LDS hand-over)
-    got = host(PD_TV_cupy(dev(x), lam, iters, mtv, nn, 8.0, 0, half))
-    assert np.array_equal(got, want_pd), ("pd K=3", shape, iters, half, mtv, nn, np.abs(got - want_pd).max())
+    for v in (21, 22):  # exact arithmetic on the SHIPPED three-iteration tiling: compiler IEEE / FMA-corrected roundings
+        ops.set_variant("pdtv", v)
+        got = host(PD_TV_cupy(dev(x), lam, iters, mtv, nn, 8.0, 0, half))
+        assert np.array_equal(got, want_pd), ("pd K=3", v, shape, iters, half, mtv, nn, np.abs(got - want_pd).max())
     want_rof = oracle.rof_tv(x, lam, iters, 0.004, half)
     got = host(ROF_TV_cupy(dev(x), lam, iters, 0.004, 0, half))
     assert np.array_equal(got, want_rof), ("rof", shape, iters, half, np.abs(got - want_rof).max())

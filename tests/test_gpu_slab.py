@@ -105,3 +105,58 @@ def test_roftv_slabs_equal_whole_volume(world, half):
         _copy_halos(states, (it + 1) & 1)
     got = torch.cat([s.local(s.U[iters & 1]) for s in states]).cpu().numpy()
     assert np.array_equal(got, want), np.abs(got - want).max()
+
+
+def test_halo_pack_unpack_round_trip():
+    """tomo_halo_pack / tomo_halo_unpack: blocks of different element sizes, odd byte counts and unaligned starts gathered
+    into one staging buffer and scattered back, byte for byte; the staging layout is the documented one (16-byte aligned
+    block starts)."""
+    import ctypes as C
+    from tomobar_amd import _lib
+    from tomobar_amd.slab import _halo_staging_bytes, _hip_halo_pack, _hip_halo_unpack
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    u = torch.rand((7, 13, 37), device="cuda", generator=g)                       # float32 planes, 13*37*4 = 1924 B each
+    p = torch.rand((7, 13, 37), device="cuda", generator=g).to(torch.float16)     # binary16 planes, 962 B each (not 4-aligned)
+    b = torch.randint(0, 255, (1001,), device="cuda", dtype=torch.uint8, generator=g)
+    blocks = [u[4:7], p[4:7], p[1:2], b[3:1000], u[0:1]]
+    nbytes = [t.numel() * t.element_size() for t in blocks]
+    total = _halo_staging_bytes(nbytes)
+    arr = (C.c_size_t * len(nbytes))(*nbytes)
+    assert _lib.lib().tomo_halo_staging_bytes(arr, len(nbytes)) == total
+    stage = torch.full((total,), 0xAB, dtype=torch.uint8, device="cuda")
+    _hip_halo_pack(blocks, nbytes, stage)
+    off = 0
+    for t, nb in zip(blocks, nbytes):
+        assert torch.equal(stage[off:off + nb], t.contiguous().view(-1).view(torch.uint8))
+        off += (nb + 15) // 16 * 16
+    outs = [torch.zeros_like(t.contiguous()) for t in blocks]
+    _hip_halo_unpack(stage, outs, nbytes)
+    torch.cuda.synchronize()
+    for t, o in zip(blocks, outs):
+        assert torch.equal(t, o)
+    with pytest.raises(ValueError):
+        _hip_halo_pack([u[0:1]] * 9, [4] * 9, stage)   # more than 8 blocks per call
+
+
+def test_pdtv_thin_volumes_direct_abi():
+    """tomo_pdtv on 3D volumes thinner than a fused launch's iteration count (dz = 1, 2) takes
+    fewer iterations per launch; checked against the oracle's 3D kernel on the same un-squeezed shape."""
+    from oracle import tomo_oracle as O
+    from tomobar_amd import ops
+    for variant in (0, 2):
+        ops.set_variant("pdtv", variant)
+        for dz in (1, 2):
+            rng = np.random.default_rng(dz)
+            x = (rng.random((dz, 9, 70)) * 0.3 + (np.indices((dz, 9, 70))[2] > 35)).astype(np.float32)
+            sigma, tau, lt, theta = O.pd_scalars(0.04, 8.0)
+            want = np.empty_like(x)
+            assert O.lib().orc_pdtv(O._fptr(x), O._fptr(want), 70, 9, dz, 3, sigma, tau, lt, theta, 7, 0, 1, 0) == 0
+            xd = torch.from_numpy(x).cuda()
+            got = torch.empty_like(xd)
+            ops.pdtv(xd, got, sigma, tau, lt, theta, 7, 0, 1, False)
+            torch.cuda.synchronize()
+            g = got.cpu().numpy()
+            err = np.linalg.norm(g - want) / np.linalg.norm(want)
+            assert err < 1e-6 and (variant != 2 or np.array_equal(g, want)), (variant, dz, err)
+    ops.set_variant("pdtv", 0)

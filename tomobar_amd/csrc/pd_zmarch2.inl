@@ -11,7 +11,7 @@
 // WX x WY waves per workgroup: WX consecutive x segments times WY consecutive row groups.  With LOCKSTEP the waves
 // of a workgroup walk z together (one barrier per plane) so that cache lines straddling two x segments and the halo
 // rows are requested by both users at the same moment and merge in the CU's L1 instead of becoming two HBM requests.
-template <typename T, int ND, bool NONNEG, bool ANISO, bool FAST, int RY, bool LOCKSTEP, int WX, int WY>
+template <typename T, int ND, bool NONNEG, bool ANISO, int FAST, int RY, bool LOCKSTEP, int WX, int WY>
 __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch2_kernel(PdArgs a, int gx, int gy, int tiles_per_xcd)
 {
     // ---- XCD-aware workgroup numbering (gx, gy count workgroups)
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch2_kernel(PdArgs a, int 
     }
 }
 
-template <typename T, int ND, bool NONNEG, bool ANISO, bool FAST, int RY, bool LOCKSTEP, int WX = 1, int WY = 4>
+template <typename T, int ND, bool NONNEG, bool ANISO, int FAST, int RY, bool LOCKSTEP, int WX = 1, int WY = 4>
 static int pd_zmarch2_launch(PdArgs a, hipStream_t st)
 {
     const int nout = a.out_end - a.out_begin;

@@ -12,7 +12,7 @@
 // stage B rows -1..RY-1 and lanes 1..61, output rows 0..RY-1 and lanes 2..61 (60 of 64).  Same workgroup shape and
 // lockstep barrier as pd_zmarch2 so that the overlapping rows / lines of neighbouring waves merge in L1.
 // Arithmetic and rounding are those of two successive single iterations (bit-identical; tests/test_gpu_parity.py).
-template <typename T, bool NONNEG, bool ANISO, bool FAST, int RY, int WX, int WY>
+template <typename T, bool NONNEG, bool ANISO, int FAST, int RY, int WX, int WY>
 __global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(1, sizeof(T) == 4 ? 2 : 8))) void pd_zmarch_x2_kernel(PdArgs a, int gx, int gy, int tiles_per_xcd)
 {
     // every XCD owns one contiguous eighth of the row-major (yb, xb) tile list: a band of rows whose halos meet in that
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(1,
     }
 }
 
-template <typename T, bool NONNEG, bool ANISO, bool FAST, int RY, int WX, int WY>
+template <typename T, bool NONNEG, bool ANISO, int FAST, int RY, int WX, int WY>
 static int pd_zmarch_x2_launch(PdArgs a, hipStream_t st)
 {
     const int nout = a.out_end - a.out_begin;

@@ -35,7 +35,7 @@ constexpr int xk_p_base(int K, int RY, int s) { return s <= 1 ? 0 : xk_p_base(K,
 constexpr int xk_in_rows(int K, int RY) { return RY + 2 * (K - 2); }
 constexpr int xk_lag_slots(int K, int RY) { return xk_p_base(K, RY, K) + K * xk_in_rows(K, RY); }
 
-template <typename T, bool NONNEG, bool ANISO, bool FAST, int K, int RY, int WX, int WY, bool LAG = false, int LREG = 0>
+template <typename T, bool NONNEG, bool ANISO, int FAST, int K, int RY, int WX, int WY, bool LAG = false, int LREG = 0>
 __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, int gx, int gy, int tiles_per_xcd)
 {
     constexpr int NR = RY + 2 * K;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
     }
 }
 
-template <typename T, bool NONNEG, bool ANISO, bool FAST, int K, int RY, int WX, int WY, bool LAG = false, int LREG = 0>
+template <typename T, bool NONNEG, bool ANISO, int FAST, int K, int RY, int WX, int WY, bool LAG = false, int LREG = 0>
 static int pd_zmarch_xk_launch(PdArgs a, hipStream_t st, long want_per_simd = 32, int min_chunk = 24)
 {
     const int nout = a.out_end - a.out_begin;

@@ -197,12 +197,32 @@ __global__ __launch_bounds__(256) void pd_pervoxel_kernel(PdArgs a)
     for (int c = 0; c < ND; ++c) DualIO<T>::st((T *)a.p_out[c], idx, p[c]);
 }
 
-// FAST = false: arithmetic and rounding of two successive single iterations (bit-identical to the oracle).
-// FAST = true : 1/(1+lt) hoisted to the host, v_rsq_f32 / v_rcp_f32 instead of IEEE sqrt + divide (<= 1e-6 relative).
-template <bool ANISO, bool FAST, int ND = 3>
+// FAST = 0: arithmetic and rounding of the reference through the compiler's IEEE sqrt / divide (bit-identical to the oracle).
+// FAST = 1: 1/(1+lt) hoisted to the host, v_rsq_f32 / v_rcp_f32 instead of IEEE sqrt + divide (<= 1e-6 relative).
+// FAST = 2: the reference's roundings reproduced with FMA correction steps (Markstein; see rof_eval in rof_zmarch.inl and
+//           tools/probes/markstein_probe.hip): sqrt = v_rsq + two coupled Newton steps + exact-residual correction,
+//           1/q and t/(1+lt) = reciprocal + exact-residual correction.  Bit-identical to FAST = 0 for normal operands
+//           (the residual underflows below ~1e-31), at about half its instruction count.
+__device__ __forceinline__ float mk_sqrt(float x)
+{
+    const float r = __builtin_amdgcn_rsqf(x);
+    float q = x * r, h = 0.5f * r;
+    const float e = fmaf(-h, q, 0.5f);
+    q = fmaf(q, e, q);
+    h = fmaf(h, e, h);
+    return fmaf(fmaf(-q, q, x), h, q);
+}
+__device__ __forceinline__ float mk_recip(float q)
+{
+    float y = __builtin_amdgcn_rcpf(q);
+    y = fmaf(fmaf(-q, y, 1.0f), y, y);
+    return fmaf(fmaf(-q, y, 1.0f), y, y);
+}
+
+template <bool ANISO, int FAST, int ND = 3>
 __device__ __forceinline__ void pd_dual_t(float (&p)[3], const float (&g)[3], float sigma)
 {
-    if (!FAST) {
+    if (FAST == 0) {
         pd_dual<ND, ANISO>(p, g, sigma);
         return;
     }
@@ -212,9 +232,17 @@ __device__ __forceinline__ void pd_dual_t(float (&p)[3], const float (&g)[3], fl
         float nrm = p[0] * p[0];
 #pragma unroll
         for (int c = 1; c < ND; ++c) nrm = fmaf(p[c], p[c], nrm);
-        const float r = nrm > 1.0f ? __builtin_amdgcn_rsqf(nrm) : 1.0f;
+        if (FAST == 2) {
+            if (nrm > 1.0f) {   // the reference's branch (primal_dual...cu:196-203): r = 1 / sqrtf(nrm), two roundings
+                const float r = mk_recip(mk_sqrt(nrm));
 #pragma unroll
-        for (int c = 0; c < ND; ++c) p[c] *= r;
+                for (int c = 0; c < ND; ++c) p[c] *= r;
+            }
+        } else {
+            const float r = nrm > 1.0f ? __builtin_amdgcn_rsqf(nrm) : 1.0f;
+#pragma unroll
+            for (int c = 0; c < ND; ++c) p[c] *= r;
+        }
     } else {
 #pragma unroll
         for (int c = 0; c < ND; ++c)
@@ -222,15 +250,16 @@ __device__ __forceinline__ void pd_dual_t(float (&p)[3], const float (&g)[3], fl
     }
 }
 
-template <bool FAST>
+template <int FAST>
 __device__ __forceinline__ float pd_primal_t(float u_in, float input, float div, float tau, float lt, float inv1lt,
                                              float theta, bool nonneg)
 {
-    if (!FAST) return pd_primal(u_in, input, div, tau, lt, theta, nonneg);
+    if (FAST == 0) return pd_primal(u_in, input, div, tau, lt, theta, nonneg);
     const float u = (nonneg && u_in < 0.0f) ? 0.0f : u_in;
     float t = fmaf(-tau, div, u);
     t = fmaf(lt, input, t);
-    const float nu = t * inv1lt;
+    float nu = t * inv1lt;
+    if (FAST == 2) nu = fmaf(fmaf(-(1.0f + lt), nu, t), inv1lt, nu);  // = t / (1 + lt) correctly rounded (inv1lt = RN(1/(1+lt)))
     return fmaf(theta, nu - u, nu);
 }
 
@@ -239,17 +268,20 @@ __device__ __forceinline__ float pd_primal_t(float u_in, float input, float div,
 #include "pd_zmarch_xk.inl"
 
 // Several iterations in one pass through HBM (3D).  `k` = iterations of this launch (2 or 3).
-//   variant 0 (shipped): float32 duals: relaxed arithmetic, k = 3 -> pd_zmarch_xk<K=3, 8 rows, 2x2 waves, LDS lag>,
-//                        k = 2 -> pd_zmarch_x2<2x4 waves>;  binary16 duals: exact arithmetic, k = 2 only (one flipped
-//                        binary16 rounding is 5e-4 of a dual value: relaxed arithmetic cannot hold the 1e-5 parity bar,
-//                        and the exact K = 3 kernel is VALU-bound: 6.4 vs 4.4 ms per iteration)
-//   variant 2: the reference's exact rounding sequence for both, k = 2 (pd_zmarch_x2, 2x2 waves; bit-identical to the oracle)
-//   variant 3: relaxed arithmetic for both, k = 2
-//   variant 21: pd_zmarch_xk K = 3 with exact arithmetic on the shipped tiling (bit-identical to the oracle)
+//   variant 0 (shipped): k = 3 -> pd_zmarch_xk<K=3, 8 rows, 2x2 waves, LDS lag>; float32 duals: relaxed arithmetic
+//                        (k = 2 remainders -> pd_zmarch_x2<2x4 waves>); binary16 duals: the reference's roundings through FMA
+//                        correction steps (FAST = 2; one flipped binary16 rounding is 5e-4 of a dual value: relaxed
+//                        arithmetic cannot hold the 1e-5 parity bar) -- round 3: 3.85 instead of 3.97 ms per iteration
+//   variant 2: the reference's exact rounding sequence through the compiler's IEEE sqrt / divide, k = 2 (pd_zmarch_x2,
+//              2x2 waves; bit-identical to the oracle)
+//   variant 3: relaxed arithmetic for both dual types, k = 2
+//   variant 21: pd_zmarch_xk K = 3 with the compiler's IEEE arithmetic on the shipped tiling (bit-identical to the oracle)
+//   variant 22: pd_zmarch_xk K = 3 with the FMA-corrected roundings for both dual types (bit-identical to the oracle;
+//               float32 duals 3.68 ms per iteration against 3.30 relaxed and 4.43 for variant 21)
 static int pd_iters_per_launch(int variant, int half)
 {
-    if (variant == 21) return 3;
-    if (variant == 0 && !half) return 3;
+    (void)half;
+    if (variant == 21 || variant == 22 || variant == 0) return 3;
     return 2;
 }
 
@@ -259,11 +291,15 @@ static int pd_iters_per_launch(int variant, int half)
 template <typename T, bool NN, bool AN>
 int pd_xk3_launch(const PdArgs &a, int variant, hipStream_t st)
 {
+    if (variant == 22) return pd_zmarch_xk_launch<T, NN, AN, 2, 3, 8, 2, 2, true, 10>(a, st);  // FMA-corrected exact roundings
     if constexpr (sizeof(T) == 4) {
-        if (variant == 21) return pd_zmarch_xk_launch<T, NN, AN, false, 3, 8, 2, 2, true, 10>(a, st);
-        return pd_zmarch_xk_launch<T, NN, AN, true, 3, 8, 2, 2, true, 10>(a, st);
+        if (variant == 21) return pd_zmarch_xk_launch<T, NN, AN, 0, 3, 8, 2, 2, true, 10>(a, st);
+        return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 2, 2, true, 10>(a, st);
     } else {
-        return pd_zmarch_xk_launch<T, NN, AN, false, 3, 4, 2, 2, true>(a, st);
+        // binary16 duals: exact roundings always (one flipped binary16 rounding is 5e-4 of a dual value); shipped = the
+        // FMA-corrected form on the 8-row tiling (3.85 ms per 1024^3 iteration; compiler IEEE on 4 rows, variant 21: 5.9)
+        if (variant == 21) return pd_zmarch_xk_launch<T, NN, AN, 0, 3, 4, 2, 2, true>(a, st);
+        return pd_zmarch_xk_launch<T, NN, AN, 2, 3, 8, 2, 2, true, 10>(a, st);
     }
 }
 
@@ -273,10 +309,11 @@ int pd_multi_launch(const PdArgs &a, int k, int methodTV, int nonneg, int varian
     constexpr bool F32 = sizeof(T) == 4;
 #define PD_XK(NN, AN)                                                                                   \
     (k == 3 ? pd_xk3_launch<T, NN, AN>(a, variant, st)                                                   \
+     : variant == 22 ? pd_zmarch_x2_launch<T, NN, AN, 2, 4, 2, 2>(a, st)                                 \
      : variant == 3  ? pd_zmarch_x2_launch<T, NN, AN, true, 4, 2, 4>(a, st)                              \
      : (variant == 2 || variant == 21) ? pd_zmarch_x2_launch<T, NN, AN, false, 4, 2, 2>(a, st)           \
      : F32 ? pd_zmarch_x2_launch<T, NN, AN, true, 4, 2, 4>(a, st)                                        \
-           : pd_zmarch_x2_launch<T, NN, AN, false, 4, 2, 2>(a, st))
+           : pd_zmarch_x2_launch<T, NN, AN, 2, 4, 2, 2>(a, st))
     int rc;
     if (!nonneg && !methodTV) rc = PD_XK(false, false);
     else if (nonneg && !methodTV) rc = PD_XK(true, false);
@@ -303,8 +340,9 @@ int pd_launch(const PdArgs &a0, int variant, hipStream_t st)
         // the shipped build (variant 0) runs float32 duals with relaxed arithmetic, like the multi-iteration kernels:
         // the arithmetic of an iteration must not depend on how a run is cut into launches (slabs cut it differently)
         const bool relaxed = (variant == 3) || (variant == 0 && sizeof(T) == 4);
-        int rc = relaxed ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, true, 8, true, 4, 2>(a, st)
-                         : pd_zmarch2_launch<T, ND, NONNEG, ANISO, false, 8, true, 4, 2>(a, st);
+        int rc = (variant == 22 || (variant == 0 && sizeof(T) == 2)) ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 2, 8, true, 4, 2>(a, st)
+                 : relaxed ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 1, 8, true, 4, 2>(a, st)
+                           : pd_zmarch2_launch<T, ND, NONNEG, ANISO, 0, 8, true, 4, 2>(a, st);
         if (rc != TOMO_OK) return rc;
     }
     TOMO_LAUNCH_CHECK();
@@ -323,7 +361,7 @@ int pd_dispatch(const PdArgs &a, int methodTV, int nonneg, int variant, hipStrea
 int pd_iter(const PdArgs &a, int nd, int methodTV, int nonneg, int half, hipStream_t st)
 {
     // 1: per-voxel kernel; 0 / 3: z-march with the shipped / relaxed arithmetic; everything else: exact z-march
-    const int v = (g_variant_pdtv == 1 || g_variant_pdtv == 0 || g_variant_pdtv == 3 || g_variant_pdtv == 11) ? (g_variant_pdtv == 11 ? 3 : g_variant_pdtv) : 2;
+    const int v = (g_variant_pdtv == 1 || g_variant_pdtv == 0 || g_variant_pdtv == 3 || g_variant_pdtv == 11 || g_variant_pdtv == 22) ? (g_variant_pdtv == 11 ? 3 : g_variant_pdtv) : 2;
     if (nd == 3) return half ? pd_dispatch<__half, 3>(a, methodTV, nonneg, v, st) : pd_dispatch<float, 3>(a, methodTV, nonneg, v, st);
     return half ? pd_dispatch<__half, 2>(a, methodTV, nonneg, v, st) : pd_dispatch<float, 2>(a, methodTV, nonneg, v, st);
 }

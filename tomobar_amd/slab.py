@@ -262,7 +262,7 @@ GHOST = 3  # ghost planes below / above an interior boundary: as deep as the lon
 
 def pd_launch_plan(iterations: int, half: bool, kmax: Optional[int] = None):
     """How tomo_pdtv cuts `iterations` into fused launches (csrc/tv_kernels.hip: step_of): `kmax` iterations per launch
-    (asked of the library: 3 for float32 duals, 2 for binary16 duals in the shipped build), as few single-iteration
+    (asked of the library: 3 in the shipped build, 2 under the exact-rounding test variant), as few single-iteration
     launches as possible (4 = 2 + 2).  The slab driver uses the same plan, so a slab run is launch for launch the
     whole-volume run."""
     if kmax is None:

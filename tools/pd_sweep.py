@@ -7,7 +7,7 @@ from tomobar_amd import ops
 from tomobar_amd.regularisersCuPy import PD_TV_cupy
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 variants = [int(v) for v in sys.argv[2:]] or [0, 2, 3, 21]
-ROUNDS, IT = 5, int(os.environ.get("PD_IT", "12"))
+ROUNDS, IT = 5, int(os.environ.get("PD_IT", "12"))   # 12 = 4 launches of 3 (or 6 of 2)
 DATA = os.environ.get("PD_DATA", "rand")
 if DATA == "phantom":   # the bench's kind of volume: piecewise-constant phantom + mild noise
     import bench
