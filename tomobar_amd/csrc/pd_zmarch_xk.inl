@@ -19,6 +19,10 @@
 // compile-time stage loop: `s` must be a constant inside the stage body.  With a run-time (unrolled) loop the code of
 // "s + 1 < K" for the last stage survives as a dead, not yet unrolled loop with variable indices into the register
 // arrays until after the last scalar-replacement pass, which then leaves the arrays in scratch memory.
+#ifndef XK_DB
+#define XK_DB 1  // rows per block of the dual / primal updates (see pd_dual_block; 4 measured 11 % slower: the first
+                 // block then waits for four rows of every input array instead of one)
+#endif
 template <typename F, int... I>
 __device__ __forceinline__ void xk_static_for_impl(F &&f, std::integer_sequence<int, I...>)
 {
@@ -36,7 +40,7 @@ constexpr int xk_in_rows(int K, int RY) { return RY + 2 * (K - 2); }
 constexpr int xk_lag_slots(int K, int RY) { return xk_p_base(K, RY, K) + K * xk_in_rows(K, RY); }
 
 template <typename T, bool NONNEG, bool ANISO, int FAST, int K, int RY, int WX, int WY, bool LAG = false, int LREG = 0>
-__global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, int gx, int gy, int tiles_per_xcd)
+__global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(2))) void pd_zmarch_xk_kernel(PdArgs a, int gx, int gy, int tiles_per_xcd)
 {
     constexpr int NR = RY + 2 * K;
     constexpr int NT = 64 * WX * WY;
@@ -75,16 +79,32 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
     int xc = min(max(x, 0), dx - 1);
     if (a.probe & 2) xc = min(max(xc, xb * WX * (64 - 2 * K)), min((xb + 1) * WX * (64 - 2 * K), dx) - 1);
 
-    unsigned off[NR];  // byte offsets of row slots -K..RY+K-1 (clamped into the volume)
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        int yy = min(max(y0 + i - K, 0), dy - 1);
-        if (a.probe & 1) yy = min(max(yy, yb * WY * RY), min((yb + 1) * WY * RY, dy) - 1);
-        off[i] = (unsigned)(yy * dx + xc) * 4u;
-    }
+    // addressing: the lane keeps ONE byte offset (its clamped column), the row of slot i is wave-uniform and goes into the
+    // buffer instruction's scalar offset (14 row offsets per lane cost 14 registers and pushed the two-path kernel into
+    // scratch).  y0 is uniform per wave; readfirstlane tells the compiler so.
+    const unsigned xo = (unsigned)xc * 4u;
+    const int wy0 = __builtin_amdgcn_readfirstlane(y0);
+    const int pitch = dx * 4;
+    // a wave whose lanes and row slots all lie strictly inside the slice takes, on planes where every stage is active
+    // and no stage sits on the first / last plane, a step without the boundary selects and activity tests (same values:
+    // each select would pick the operand the short form uses).  Wave-uniform, kept in an SGPR.
+    const int x_w0 = xs * (64 - 2 * K) - K;
+    const bool xy_inner = __builtin_amdgcn_readfirstlane(
+        (int)(x_w0 >= 1 && x_w0 + 63 <= dx - 2 && y0 - K >= 1 && y0 + RY + K - 1 <= dy - 2)) != 0;
     const PlaneIO io{(int)(sz * 4)};  // plane-relative buffer addressing, see tv_kernels.hip
-    auto ldf = [&](const float *base, unsigned boff) { return io.ldf(base, boff); };
-    auto ldd = [&](const T *base, unsigned boff) { return io.ldd(base, boff); };
+    const PlaneIO io_pin{a.p_in_zero ? 0 : (int)(sz * 4)};  // input duals of the short form (see there)
+    // byte offset of row slot i (rows -K .. RY+K-1) inside a float plane; EDGE: clamped into the slice
+    auto rowoff = [&](int i, auto ec) __attribute__((always_inline)) {
+        if constexpr (!decltype(ec)::value) {
+            int yy = wy0 + i - K;
+            if (a.probe & 1) yy = min(max(yy, yb * WY * RY), min((yb + 1) * WY * RY, dy) - 1);  // measurement only (uniform)
+            return yy * pitch;
+        } else {
+            int yy = min(max(wy0 + i - K, 0), dy - 1);
+            if (a.probe & 1) yy = min(max(yy, yb * WY * RY), min((yb + 1) * WY * RY, dy) - 1);
+            return yy * pitch;
+        }
+    };
     const T *P_in[3] = {(const T *)a.p_in[0], (const T *)a.p_in[1], (const T *)a.p_in[2]};
     T *P_out[3] = {(T *)a.p_out[0], (T *)a.p_out[1], (T *)a.p_out[2]};
 
@@ -114,38 +134,56 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
     {
         const float *up = a.u_in + sz * zA;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) U0c[i] = ldf(up, off[i]);
+        for (int i = 0; i < NR; ++i) U0c[i] = io.ldf(up, xo, rowoff(i, std::true_type{}));
     }
 
-    for (int t = zA; t <= tEnd; ++t) {
-        __syncthreads();  // lockstep: lines shared with the neighbouring waves merge in L1 (see pd_zmarch2)
+    auto step = [&](const int t, auto ec) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(ec)::value;  // false: the short form (interior wave, steady planes)
         float U0n[NR];
         float Pw[3][NR];
         float Pnext[K][3][NR];
 #pragma unroll
-        for (int i = 0; i < NR; ++i) { U0n[i] = 0.0f; Pw[0][i] = 0.0f; Pw[1][i] = 0.0f; Pw[2][i] = 0.0f; }
-        const bool act0 = (t < dz);
+        for (int i = 0; i < NR; ++i) {
+            U0n[i] = 0.0f;
+            if constexpr (EDGE) { Pw[0][i] = 0.0f; Pw[1][i] = 0.0f; Pw[2][i] = 0.0f; }
+        }
+        const bool act0 = !EDGE || (t < dz);
         if (act0) {
-            const bool z_last = (t == dz - 1) && a.last_is_edge;
+            const bool z_last = EDGE && (t == dz - 1) && a.last_is_edge;
             const int zn = z_last ? max(t - 1, 0) : min(t + 1, dz - 1);
-            const float *up = a.u_in + sz * zn;
+            const float *up = a.u_in + sz * ((a.probe & 4) ? 0 : zn);
 #pragma unroll
-            for (int i = 0; i < NR; ++i) U0n[i] = ldf(up, off[i]);
+            for (int i = 0; i < NR; ++i) U0n[i] = io.ldf(up, xo, rowoff(i, ec));
             if (z_last && t == 0) {
 #pragma unroll
                 for (int i = 0; i < NR; ++i) U0n[i] = 0.0f;
             }
-            if (!a.p_in_zero) {  // uniform: the first launch of a prox starts from zero duals (nothing to read)
+            if constexpr (!EDGE) {
+                // short form: no test.  On the first launch of a prox (duals are zero, nothing to read) the descriptor has
+                // zero records: the range check answers every load with 0 and no request leaves the CU.
+                // Requests go out row by row (U of the next plane was requested above, in row order, too): loads return in
+                // order, so the dual update of row i can start once ITS four values are there.
+                const T *pp0 = P_in[0] + sz * ((a.probe & 4) ? 0 : t);
+                const T *pp1 = P_in[1] + sz * ((a.probe & 4) ? 0 : t);
+                const T *pp2 = P_in[2] + sz * ((a.probe & 4) ? 0 : t);
+#pragma unroll
+                for (int i = 0; i < NR - 1; ++i) {
+                    Pw[0][i] = io_pin.ldd(pp0, xo, rowoff(i, ec));
+                    Pw[1][i] = io_pin.ldd(pp1, xo, rowoff(i, ec));
+                    Pw[2][i] = io_pin.ldd(pp2, xo, rowoff(i, ec));
+                }
+                Pw[0][NR - 1] = 0.0f; Pw[1][NR - 1] = 0.0f; Pw[2][NR - 1] = 0.0f;
+            } else if (!a.p_in_zero) {  // uniform: the first launch of a prox starts from zero duals (nothing to read)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const T *pp = P_in[c] + sz * t;
+                    const T *pp = P_in[c] + sz * ((a.probe & 4) ? 0 : t);
 #pragma unroll
-                    for (int i = 0; i < NR - 1; ++i) Pw[c][i] = ldd(pp, off[i]);
+                    for (int i = 0; i < NR - 1; ++i) Pw[c][i] = io.ldd(pp, xo, rowoff(i, ec));
                 }
             }
-            const float *ip = a.in + sz * t;
+            const float *ip = a.in + sz * ((a.probe & 4) ? 0 : t);
 #pragma unroll
-            for (int i = 1; i < NR - 1; ++i) In[0][i] = ldf(ip, off[i]);
+            for (int i = 1; i < NR - 1; ++i) In[0][i] = io.ldf(ip, xo, rowoff(i, ec));
             if (LAG) {  // Input(t) for the later stages: ring slot t mod K
                 const int q = t % K;
 #pragma unroll
@@ -155,12 +193,12 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
         xk_static_for<K>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
             const int p = t - s;                                 // plane of this stage
-            const bool act = (p >= max(zc0 - (K - s), 0)) && (p < dz) && (s > 0 || act0);
+            const bool act = !EDGE || ((p >= max(zc0 - (K - s), 0)) && (p < dz) && (s > 0 || act0));
             float Vn[NR];                                        // U^{n+s+1}(p), rows -(K-s-1) .. RY+(K-s-1)-1
 #pragma unroll
             for (int i = 0; i < NR; ++i) Vn[i] = 0.0f;
             if (act) {
-                const bool p_last = (p == dz - 1) && a.last_is_edge;
+                const bool p_last = EDGE && (p == dz - 1) && a.last_is_edge;
                 if constexpr (s > 0 && !LAG) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
@@ -175,49 +213,76 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
 #pragma unroll
                     for (int r = -(K - s - 1); r <= RY + (K - s - 1) - 1; ++r) InS[r + K] = lag[IN_BASE - LREG + q * IN_ROWS + (r + K - 2)][tid];
                 }
-                // ---------------- duals, rows -(K-s) .. RY+(K-s)-2
+                // ---------------- duals, rows -(K-s) .. RY+(K-s)-2, four rows at a time (see pd_dual_block)
+                constexpr int DB = XK_DB, D0 = -(K - s), D1 = RY + (K - s) - 2;
 #pragma unroll
-                for (int r = -(K - s); r <= RY + (K - s) - 2; ++r) {
-                    const int i = r + K;
-                    const int y = y0 + r;
-                    const float u = (s == 0) ? U0c[i] : Ur[s][1][i];
-                    const float ux = __shfl_down(u, 1, 64);
-                    const float uxm = __shfl_up(u, 1, 64);
-                    float g[3];
-                    g[0] = (x_last ? (x_has_prev ? uxm : 0.0f) : ux) - u;
-                    const float u_up = (s == 0) ? U0c[i > 0 ? i - 1 : 0] : Ur[s][1][i > 0 ? i - 1 : 0];
-                    const float u_dn = (s == 0) ? U0c[i + 1] : Ur[s][1][i + 1];
-                    const float uy_mirror = (y > 0) ? u_up : 0.0f;  // the first row slot is never the volume's last row
-                    g[1] = ((y == dy - 1) ? uy_mirror : u_dn) - u;
-                    float uz;
-                    if (s == 0) uz = U0n[i];  // stage 0: the loaded plane is already the mirrored one at the far edge
-                    else uz = p_last ? ((p > 0) ? Ur[s][0][i] : 0.0f) : Ur[s][2][i];
-                    g[2] = uz - u;
-                    float pv[3] = {Pw[0][i], Pw[1][i], Pw[2][i]};
-                    pd_dual_t<ANISO, FAST>(pv, g, a.sigma);
-                    Pw[0][i] = pv[0]; Pw[1][i] = pv[1]; Pw[2][i] = pv[2];
+                for (int rb = D0; rb <= D1; rb += DB) {
+                    float gg[DB][3], pv[DB][3];
+#pragma unroll
+                    for (int k = 0; k < DB; ++k) {
+                        const int r = rb + k <= D1 ? rb + k : D1;  // (a short last block repeats its last row: unused)
+                        const int i = r + K;
+                        const int y = y0 + r;
+                        const float u = (s == 0) ? U0c[i] : Ur[s][1][i];
+                        const float ux = __shfl_down(u, 1, 64);
+                        const float uxm = __shfl_up(u, 1, 64);
+                        gg[k][0] = (EDGE ? (x_last ? (x_has_prev ? uxm : 0.0f) : ux) : ux) - u;
+                        const float u_up = (s == 0) ? U0c[i > 0 ? i - 1 : 0] : Ur[s][1][i > 0 ? i - 1 : 0];
+                        const float u_dn = (s == 0) ? U0c[i + 1] : Ur[s][1][i + 1];
+                        const float uy_mirror = (y > 0) ? u_up : 0.0f;  // the first row slot is never the volume's last row
+                        gg[k][1] = (EDGE ? ((y == dy - 1) ? uy_mirror : u_dn) : u_dn) - u;
+                        float uz;
+                        if (s == 0) uz = U0n[i];  // stage 0: the loaded plane is already the mirrored one at the far edge
+                        else uz = p_last ? ((p > 0) ? Ur[s][0][i] : 0.0f) : Ur[s][2][i];
+                        gg[k][2] = uz - u;
+                        pv[k][0] = Pw[0][i]; pv[k][1] = Pw[1][i]; pv[k][2] = Pw[2][i];
+                    }
+                    constexpr int left = D1 - D0 + 1;
+                    const int nrows = (rb - D0 + DB <= left) ? DB : left - (rb - D0);
+                    pd_dual_block<ANISO, FAST, DB>(pv, gg, a.sigma, nrows);
+#pragma unroll
+                    for (int k = 0; k < DB; ++k) {
+                        if (rb + k <= D1) {
+                            const int i = rb + k + K;
+                            Pw[0][i] = pv[k][0]; Pw[1][i] = pv[k][1]; Pw[2][i] = pv[k][2];
+                        }
+                    }
                 }
-                // ---------------- primal, rows -(K-s-1) .. RY+(K-s-1)-1
-                const bool emit_plane = (s == K - 1) && (p >= zc0);
+                // ---------------- primal, rows -(K-s-1) .. RY+(K-s-1)-1, four rows at a time
+                const bool emit_plane = (s == K - 1) && (!EDGE || p >= zc0);
+                constexpr int Q0 = -(K - s - 1), Q1 = RY + (K - s - 1) - 1;
 #pragma unroll
-                for (int r = -(K - s - 1); r <= RY + (K - s - 1) - 1; ++r) {
-                    const int i = r + K;
-                    const int y = y0 + r;
-                    const float p1l = __shfl_up(Pw[0][i], 1, 64);
-                    const float px = x_has_prev ? p1l : 0.0f;
-                    const float py = (y > 0) ? Pw[1][i - 1] : 0.0f;
-                    const float pz = (p > 0) ? c3[s][i] : 0.0f;
-                    float div = (-(Pw[0][i] - px)) + (-(Pw[1][i] - py));
-                    div = div + (-(Pw[2][i] - pz));
-                    const float u = (s == 0) ? U0c[i] : Ur[s][1][i];
-                    const float uo = pd_primal_t<FAST>(u, InS[i], div, a.tau, a.lt, a.inv1lt, a.theta, NONNEG);
-                    Vn[i] = uo;
-                    if constexpr (s == K - 1) {
-                        if (emit_plane && emit_lane && y < dy) {
-                            io.stf(a.u_out + sz * p, off[i], uo);
-                            if (!a.p_out_skip) {  // uniform: nobody reads the duals of the last launch of a prox
+                for (int rb = Q0; rb <= Q1; rb += DB) {
+                    float uu[DB], in4[DB], dv[DB], uo[DB];
 #pragma unroll
-                                for (int c = 0; c < 3; ++c) io.std_(P_out[c] + sz * p, off[i], Pw[c][i]);
+                    for (int k = 0; k < DB; ++k) {
+                        const int r = rb + k <= Q1 ? rb + k : Q1;
+                        const int i = r + K;
+                        const int y = y0 + r;
+                        const float p1l = __shfl_up(Pw[0][i], 1, 64);
+                        const float px = (!EDGE || x_has_prev) ? p1l : 0.0f;
+                        const float py = (!EDGE || y > 0) ? Pw[1][i - 1] : 0.0f;
+                        const float pz = (!EDGE || p > 0) ? c3[s][i] : 0.0f;
+                        float div = (-(Pw[0][i] - px)) + (-(Pw[1][i] - py));
+                        dv[k] = div + (-(Pw[2][i] - pz));
+                        uu[k] = (s == 0) ? U0c[i] : Ur[s][1][i];
+                        in4[k] = InS[i];
+                    }
+                    pd_primal_block<FAST, DB>(uo, uu, in4, dv, a.tau, a.lt, a.inv1lt, a.theta, NONNEG);
+#pragma unroll
+                    for (int k = 0; k < DB; ++k) {
+                        if (rb + k <= Q1) {
+                            const int i = rb + k + K;
+                            const int y = y0 + rb + k;
+                            Vn[i] = uo[k];
+                            if constexpr (s == K - 1) {
+                                if (emit_plane && emit_lane && (!EDGE || y < dy)) {
+                                    io.stf(a.u_out + sz * ((a.probe & 4) ? 0 : p), xo, rowoff(i, ec), uo[k]);
+                                    if (!a.p_out_skip) {  // uniform: nobody reads the duals of the last launch of a prox
+#pragma unroll
+                                        for (int c = 0; c < 3; ++c) io.std_(P_out[c] + sz * ((a.probe & 4) ? 0 : p), xo, rowoff(i, ec), Pw[c][i]);
+                                    }
+                                }
                             }
                         }
                     }
@@ -232,7 +297,8 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
             if constexpr (s + 1 < K) {
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
-                    Ur[s + 1][0][i] = Ur[s + 1][1][i];
+                    // plane p-1 is only read by the far-edge mirror, at least one general step after the short form ended
+                    if constexpr (EDGE) Ur[s + 1][0][i] = Ur[s + 1][1][i];
                     Ur[s + 1][1][i] = Ur[s + 1][2][i];
                     Ur[s + 1][2][i] = Vn[i];
                 }
@@ -280,6 +346,33 @@ __global__ __launch_bounds__(64 * WX * WY) void pd_zmarch_xk_kernel(PdArgs a, in
         if (act0) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) U0c[i] = U0n[i];
+        }
+    };
+
+    // short form: every stage active (t >= zc0 + K - 2, t >= K - 1, t < dz), no stage on plane 0 (t >= K) or on the last
+    // plane (t <= dz - 2), the last stage emits (t - K + 1 >= zc0).  The march is cut into [general | short | general]
+    // ranges run by SEPARATE loops (an interior wave: warm-up planes, steady planes, drain; any other wave: everything in
+    // the first general range): with both forms inside one loop the loop-carried state had to sit in the same registers
+    // for both and the allocator spilled inside the march.  Every wave passes the barrier once per plane either way.
+    const int tS0 = xy_inner ? min(max(zc0 + K - 1, K), tEnd + 1) : tEnd + 1;
+    const int tS1 = xy_inner ? max(min(dz - 2, tEnd), tS0 - 1) : tEnd;
+    for (int phase = 0; phase < 2; ++phase) {  // (one copy of the general form's code for both of its ranges)
+        const int e0 = phase == 0 ? zA : tS1 + 1, e1 = phase == 0 ? tS0 - 1 : tEnd;
+        for (int t = e0; t <= e1; ++t) {
+            __syncthreads();  // lockstep: lines shared with the neighbouring waves merge in L1 (see pd_zmarch2)
+            step(t, std::true_type{});
+        }
+        if (phase == 0 && tS0 <= tS1) {
+            for (int t = tS0; t <= tS1; ++t) {
+                __syncthreads();
+                step(t, std::false_type{});
+            }
+            // the short form does not maintain plane p-1 of the later stages; nothing reads it before the next general
+            // step has rotated it in again (that step is at most dz - 1, where only stage 0 sits on the last plane)
+#pragma unroll
+            for (int s = 1; s < K; ++s)
+#pragma unroll
+                for (int i = 0; i < NR; ++i) Ur[s][0][i] = 0.0f;
         }
     }
 }

@@ -28,11 +28,11 @@ namespace {
 // never consumed.
 __device__ __forceinline__ float wave_prev(float v)  // lane i <- lane i-1
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float wave_next(float v)  // lane i <- lane i+1
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
 }
 #ifndef TOMO_TV_NO_DPP
 #define __shfl_up(v, d, w) wave_prev(v)
@@ -80,6 +80,29 @@ struct PlaneIO {
     __device__ __forceinline__ void stf(float *plane, unsigned boff, float v) const
     {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs(plane, bytes), (int)boff, 0, 0);
+    }
+    // (lane column offset, wave-uniform row offset) forms: `xo` = FLOAT byte offset of the lane's column inside a row
+    // (VGPR), `ro` = FLOAT byte offset of the row inside the plane (SGPR, goes into the instruction's soffset).  The
+    // range check of a raw buffer covers the lane offset only, so `ro + xo` must lie inside the plane.
+    __device__ __forceinline__ float ldf(const float *plane, unsigned xo, int ro) const
+    {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs(plane, bytes), (int)xo, ro, 0));
+    }
+    __device__ __forceinline__ void stf(float *plane, unsigned xo, int ro, float v) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs(plane, bytes), (int)xo, ro, 0);
+    }
+    __device__ __forceinline__ float ldd(const float *plane, unsigned xo, int ro) const { return ldf(plane, xo, ro); }
+    __device__ __forceinline__ void std_(float *plane, unsigned xo, int ro, float v) const { stf(plane, xo, ro, v); }
+    __device__ __forceinline__ float ldd(const __half *plane, unsigned xo, int ro) const
+    {
+        const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(rs(plane, bytes >> 1), (int)(xo >> 1), ro >> 1, 0);
+        return __half2float(__builtin_bit_cast(__half, h));
+    }
+    __device__ __forceinline__ void std_(__half *plane, unsigned xo, int ro, float v) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, f32_to_half_twice_rounded(v)), rs(plane, bytes >> 1),
+                                              (int)(xo >> 1), ro >> 1, 0);
     }
     // dual fields: float or binary16 (boff is always the FLOAT byte offset of the voxel)
     __device__ __forceinline__ float ldd(const float *plane, unsigned boff) const { return ldf(plane, boff); }
@@ -147,7 +170,7 @@ struct PdArgs {
     float inv1lt;     // 1 / (1 + lt), relaxed-arithmetic kernels only
     int p_in_zero = 0;   // pd_zmarch_xk: the input duals are all zero (first launch of a prox): do not read them
     int p_out_skip = 0;  // pd_zmarch_xk: do not store the output duals (last launch of a prox)
-    int probe = 0;       // measurement only (tools/pd_halo_probe.py): 1 = alias the y halo rows, 2 = the x halo lanes onto the workgroup's own tile
+    int probe = 0;       // measurement only (tools/pd_halo_probe.py): 1 = alias the y halo rows, 2 = the x halo lanes onto the workgroup's own tile, 4 = every plane access goes to plane 0 (cache-resident: what the kernel costs without HBM)
 };
 
 // ------------------------------------------------------------------------------------------ PD variant 1
@@ -233,11 +256,13 @@ __device__ __forceinline__ void pd_dual_t(float (&p)[3], const float (&g)[3], fl
 #pragma unroll
         for (int c = 1; c < ND; ++c) nrm = fmaf(p[c], p[c], nrm);
         if (FAST == 2) {
-            if (nrm > 1.0f) {   // the reference's branch (primal_dual...cu:196-203): r = 1 / sqrtf(nrm), two roundings
-                const float r = mk_recip(mk_sqrt(nrm));
+            // the reference's branch (primal_dual...cu:196-203): if (nrm > 1) p *= 1 / sqrtf(nrm), two roundings.  Branch-free
+            // (p * 1.0f is p exactly): the correction steps of neighbouring rows then pack into v_pk_fma_f32, and a wave
+            // with one lane over the threshold paid for the whole sequence anyway.
+            const float r = mk_recip(mk_sqrt(nrm));
+            const float rr = nrm > 1.0f ? r : 1.0f;
 #pragma unroll
-                for (int c = 0; c < ND; ++c) p[c] *= r;
-            }
+            for (int c = 0; c < ND; ++c) p[c] *= rr;
         } else {
             const float r = nrm > 1.0f ? __builtin_amdgcn_rsqf(nrm) : 1.0f;
 #pragma unroll
@@ -247,6 +272,63 @@ __device__ __forceinline__ void pd_dual_t(float (&p)[3], const float (&g)[3], fl
 #pragma unroll
         for (int c = 0; c < ND; ++c)
             p[c] = fabsf(p[c]) > 1.0f ? copysignf(1.0f, p[c]) : p[c];  // p / |p| is exactly +-1 in IEEE arithmetic too
+    }
+}
+
+// The dual update of NB independent rows, written phase by phase across the rows (FAST = 2 only; the other levels just
+// loop).  A dependent v_pk_*_f32 needs one wait state after its producer; row by row the correction chain of a row pair
+// is eleven dependent packed operations and the compiler fills every gap with an s_nop (147 per step of the K = 3
+// kernel).  With the chains of two row pairs interleaved in program order the other pair's operation sits in the gap.
+// Same operations on the same operands as pd_dual_t: identical results.
+template <bool ANISO, int FAST, int NB>
+__device__ __forceinline__ void pd_dual_block(float (&p)[NB][3], const float (&g)[NB][3], float sigma, int n)
+{
+    if constexpr (FAST != 2 || ANISO) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (k < n) pd_dual_t<ANISO, FAST>(p[k], g[k], sigma);
+    } else {
+        float nrm[NB], q[NB], h[NB], e[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[k][c] = fmaf(sigma, g[k][c], p[k][c]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) nrm[k] = p[k][0] * p[k][0];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) nrm[k] = fmaf(p[k][1], p[k][1], nrm[k]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) nrm[k] = fmaf(p[k][2], p[k][2], nrm[k]);
+        // mk_sqrt
+#pragma unroll
+        for (int k = 0; k < NB; ++k) e[k] = __builtin_amdgcn_rsqf(nrm[k]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { q[k] = nrm[k] * e[k]; h[k] = 0.5f * e[k]; }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) e[k] = fmaf(-h[k], q[k], 0.5f);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { q[k] = fmaf(q[k], e[k], q[k]); h[k] = fmaf(h[k], e[k], h[k]); }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) e[k] = fmaf(-q[k], q[k], nrm[k]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) q[k] = fmaf(e[k], h[k], q[k]);   // = sqrtf(nrm)
+        // mk_recip
+#pragma unroll
+        for (int k = 0; k < NB; ++k) h[k] = __builtin_amdgcn_rcpf(q[k]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) e[k] = fmaf(-q[k], h[k], 1.0f);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) h[k] = fmaf(e[k], h[k], h[k]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) e[k] = fmaf(-q[k], h[k], 1.0f);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) h[k] = fmaf(e[k], h[k], h[k]);   // = 1.0f / sqrtf(nrm)
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const float rr = nrm[k] > 1.0f ? h[k] : 1.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[k][c] *= rr;
+        }
     }
 }
 
@@ -261,6 +343,38 @@ __device__ __forceinline__ float pd_primal_t(float u_in, float input, float div,
     float nu = t * inv1lt;
     if (FAST == 2) nu = fmaf(fmaf(-(1.0f + lt), nu, t), inv1lt, nu);  // = t / (1 + lt) correctly rounded (inv1lt = RN(1/(1+lt)))
     return fmaf(theta, nu - u, nu);
+}
+
+// the primal update of NB independent rows, phase by phase (see pd_dual_block); same operations as pd_primal_t
+template <int FAST, int NB>
+__device__ __forceinline__ void pd_primal_block(float (&out)[NB], const float (&u_in)[NB], const float (&input)[NB],
+                                                const float (&div)[NB], float tau, float lt, float inv1lt, float theta,
+                                                bool nonneg)
+{
+    if constexpr (FAST == 0) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) out[k] = pd_primal(u_in[k], input[k], div[k], tau, lt, theta, nonneg);
+    } else {
+        float u[NB], t[NB], nu[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) u[k] = (nonneg && u_in[k] < 0.0f) ? 0.0f : u_in[k];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) t[k] = fmaf(-tau, div[k], u[k]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) t[k] = fmaf(lt, input[k], t[k]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) nu[k] = t[k] * inv1lt;
+        if constexpr (FAST == 2) {  // = t / (1 + lt) correctly rounded (inv1lt = RN(1/(1+lt)))
+#pragma unroll
+            for (int k = 0; k < NB; ++k) t[k] = fmaf(-(1.0f + lt), nu[k], t[k]);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) nu[k] = fmaf(t[k], inv1lt, nu[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) u[k] = nu[k] - u[k];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) out[k] = fmaf(theta, u[k], nu[k]);
+    }
 }
 
 #include "pd_zmarch2.inl"
@@ -281,7 +395,7 @@ __device__ __forceinline__ float pd_primal_t(float u_in, float input, float div,
 static int pd_iters_per_launch(int variant, int half)
 {
     (void)half;
-    if (variant == 21 || variant == 22 || variant == 0) return 3;
+    if (variant == 21 || variant == 22 || variant == 31 || variant == 0) return 3;
     return 2;
 }
 
@@ -292,6 +406,7 @@ template <typename T, bool NN, bool AN>
 int pd_xk3_launch(const PdArgs &a, int variant, hipStream_t st)
 {
     if (variant == 22) return pd_zmarch_xk_launch<T, NN, AN, 2, 3, 8, 2, 2, true, 10>(a, st);  // FMA-corrected exact roundings
+    if (variant == 31) return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 2, 2, true, 10>(a, st);  // measurement: relaxed for both dual types
     if constexpr (sizeof(T) == 4) {
         if (variant == 21) return pd_zmarch_xk_launch<T, NN, AN, 0, 3, 8, 2, 2, true, 10>(a, st);
         return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 2, 2, true, 10>(a, st);

@@ -13,7 +13,7 @@ vol = torch.rand((N, N, N), device="cuda")
 out = torch.empty_like(vol)
 res = {}
 for rnd in range(4):
-    for probe in (0, 1, 2, 3):
+    for probe in (0, 1, 2, 3, 4):
         ops.set_variant("probe", probe)
         if rnd == 0:
             PD_TV_cupy(vol, 0.01, 3, 0, 1, 12.0, 0, False, out=out)
