@@ -163,6 +163,30 @@ __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
             for (int aa = 0; aa < nb; ++aa) sample(aa);
         }
     }
+    // ---- epilogue.  A brick that lies inside the volume hands its 32 x 16 x 16 accumulators over through LDS (the tile
+    // buffers are free now) so that a lane owns four consecutive voxels of a row: 8 dwordx4 accesses per thread and array
+    // in whole 128-byte lines instead of 32 dword accesses in 64-byte row pieces (the fused FISTA epilogue cost +1.9 ms
+    // per 1024^3 call for +0.9 ms of compulsory traffic).  Same arithmetic per voxel.
+    const bool vec_ok = (tx0 + BB_TX <= a.n) && (ty0 + BB_TY <= a.n) && (z0 + 4 * BB_ZQ <= a.nz) && ((a.n & 3) == 0) && a.epi_aligned
+                        && EPI != EPI_PLAIN;  // (plain stores gain nothing: 7.26 -> 7.32 ms)
+    if (vec_ok) {  // uniform for the workgroup
+        float *stg = reinterpret_cast<float *>(&tile2[0][0]);  // [16 z][16 y][32 x] floats = 32 KiB of the 40
+        __syncthreads();  // every wave is past the sampling of the last batch
+        const int xr = ix - tx0, yr = iy0 - ty0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 4 * BB_ZQ; ++j) stg[(j * BB_TY + yr + 4 * r) * BB_TX + xr] = acc[r][j >> 1][j & 1];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4 * BB_ZQ * BB_TY * (BB_TX / 4) / 256; ++m) {
+            const int item = tid + 256 * m;  // float4 index = (z * 16 + y) * 8 + x4
+            const int x4 = item & (BB_TX / 4 - 1), yy = (item / (BB_TX / 4)) & (BB_TY - 1), zz = item / (BB_TX / 4 * BB_TY);
+            const float4 g = reinterpret_cast<const float4 *>(stg)[item];
+            bp_epilogue4<EPI>(a, ((size_t)(z0 + zz) * a.n + (ty0 + yy)) * a.n + tx0 + 4 * x4, g);
+        }
+        return;
+    }
     if (ix < a.n) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {

@@ -494,9 +494,10 @@ struct RofArgs {
 __device__ __forceinline__ float rof_mm(float n0, float n1)
 {
     // (0.5*(sign(n1)+sign(n0)) * min(|n1|,|n0|))^2   (rudin_osher...cu:51-55)
-    int sg = ((n1 > 0.0f) - (n1 < 0.0f)) + ((n0 > 0.0f) - (n0 < 0.0f));
-    float m = fminf(fabsf(n1), fabsf(n0));
-    m = (sg == 0) ? 0.0f : (sg > 0 ? m : -m);
+    // = min(|n1|,|n0|)^2 where both have the same sign and neither is zero, else 0.  max(min(n1,n0), min(-n1,-n0)) is
+    // min(|n1|,|n0|) for equal signs, <= 0 otherwise (0 when one of them is zero): two v_min, one v_max3, one multiply
+    // instead of the twelve compare / select / carry operations of the sign arithmetic; (+-m)^2 rounds like m^2.
+    const float m = fmaxf(fmaxf(fminf(n1, n0), fminf(-n1, -n0)), 0.0f);
     return m * m;
 }
 
