@@ -781,7 +781,7 @@ extern "C" int tomo_pdtv_multi_slab_range(int device, const float *in_dev, const
     tomo_prof_scope prof(PROF_PDTV, st, 1);
     // slabs always run the per-wave-halo kernels: shipped arithmetic (0), relaxed for both dual types (3), else exact;
     // an exact three-iteration launch is variant 21
-    int v = (g_variant_pdtv == 0 || g_variant_pdtv == 3) ? g_variant_pdtv : 2;
+    int v = (g_variant_pdtv == 0 || g_variant_pdtv == 3 || g_variant_pdtv == 22) ? g_variant_pdtv : 2;
     if (k == 3 && v == 2) v = 21;
     return half ? pd_multi_launch<__half>(a, k, methodTV, nonneg, v, st) : pd_multi_launch<float>(a, k, methodTV, nonneg, v, st);
 }

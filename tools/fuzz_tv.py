@@ -13,7 +13,7 @@ for seed in range(300):
     half, mtv, nn = bool(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
     lam = float(rng.choice([0.01, 0.05, 0.3]))
     want = oracle.pd_tv(x, lam, iters, mtv, nn, 8.0, half)
-    for v in (21, 2):
+    for v in (21, 2, 22):
         ops.set_variant("pdtv", v)
         got = PD_TV_cupy(torch.from_numpy(x).cuda(), lam, iters, mtv, nn, 8.0, 0, half).cpu().numpy()
         if not np.array_equal(got, want):
@@ -21,9 +21,9 @@ for seed in range(300):
     ops.set_variant("pdtv", 0)
     got = PD_TV_cupy(torch.from_numpy(x).cuda(), lam, iters, mtv, nn, 8.0, 0, half).cpu().numpy()
     r = np.linalg.norm((got - want).ravel().astype(np.float64)) / max(np.linalg.norm(want.ravel().astype(np.float64)), 1e-30)
-    if r > 1e-5:
-        bad += 1; print("RELAXED", shape, iters, half, mtv, nn, r, flush=True)
-    ops.set_variant("roftv", 2)
+    if r > 1e-5 or (half and not np.array_equal(got, want)):   # binary16 duals ship exact roundings
+        bad += 1; print("SHIPPED", shape, iters, half, mtv, nn, r, flush=True)
+    ops.set_variant("roftv", 0)   # the shipped ROF_TV reproduces the reference's roundings
     wr = oracle.rof_tv(x, lam, iters, 0.004, half)
     got = ROF_TV_cupy(torch.from_numpy(x).cuda(), lam, iters, 0.004, 0, half).cpu().numpy()
     if not np.array_equal(got, wr):
