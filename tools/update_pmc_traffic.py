@@ -1,8 +1,8 @@
 """Rebuild profiles/pmc_traffic.json from rocprofv3 --pmc passes (tools/pmc_run.sh) of the CURRENT kernel sources.
 usage: python tools/update_pmc_traffic.py <pdtv-dir> <others-dir> <profile-name>
   <pdtv-dir>   gpurun_out/pmc_<tag> holding pdtv0_g0 (FETCH_SIZE) / pdtv0_g1 (WRITE_SIZE) of a 9-iteration prox
-               (first + middle + last launch)
-  <others-dir> the same for pdtv0h, roftv, bp0, fp
+               (first + middle + last launch), and the same for pdtv0h (binary16 duals)
+  <others-dir> the same for roftv, bp0, fp
 FETCH_SIZE is doubled (MI355X_MICROARCH.md: 128-B requests are counted as 64 B); values are KiB."""
 import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,8 +34,17 @@ out["pdtv"] = {
     "traffic_bytes_first_middle_last": tr,
     "sources_sha16": bench.source_hash("pdtv"), "profile": profile,
     "note": "traffic_bytes = (first + last + 8 x middle) / 10, the per-launch mean of the bench's 30-iteration prox"}
+fh, wh = vals(pd_dir, "pdtv0h", 0, "xk_kernel"), vals(pd_dir, "pdtv0h", 1, "xk_kernel")
+assert len(fh) == 3 and len(wh) == 3, (fh, wh)
+trh = [traffic(a, b) for a, b in zip(fh, wh)]
+out["pdtv_half"] = {
+    "workload": "1024^3 binary16 duals, 3 iterations/launch (pd_zmarch_xk K=3, 8 rows, FMA-corrected exact roundings); "
+                "first / middle / last launch of a prox",
+    "fetch_kib_raw": [fh[0], fh[1], fh[2]], "write_kib": [wh[0], wh[1], wh[2]],
+    "traffic_bytes": (trh[0] + trh[2] + 8 * trh[1]) / 10.0,
+    "traffic_bytes_first_middle_last": trh,
+    "sources_sha16": bench.source_hash("pdtv"), "profile": profile}
 for name, what, keys, wl in (
-        ("pdtv_half", "pdtv0h", ["x2_kernel"], "1024^3 f16 duals, 2 iterations/launch (pd_zmarch_x2, exact arithmetic); middle launch"),
         ("roftv", "roftv", ["rof_"], "1024^3, 1 iteration/launch (rof_zmarch, shipped build: FMA-corrected reference roundings); later launches"),
         ("bp", "bp0", ["bp_brick"], "1024^3, 75 angles (one subset), bp_brick_kernel"),
         ("fp", "fp", ["fp_tiled", "transpose"], "1024^3, 75 angles (one subset): 2 launches of fp_tiled_kernel<...,1024> + the in-plane transpose")):
