@@ -132,8 +132,11 @@ def test_power_method_literals(oracle):
         np.testing.assert_allclose(rt.powermethod(dict(dummy)), literal, rtol=1e-5)
 
 
-def test_fused_residual_and_gradient_steps(oracle, ops):
-    g = (6, 36, 40, 22, 0.5, 3)
+@pytest.mark.parametrize("g", [(6, 36, 40, 22, 0.5, 3),
+                               # 3 x 6 x 2 whole 32x16x16 bricks (epilogue through LDS in dwordx4 row segments) next to
+                               # ragged ones in x, y and z (direct stores) in the same launch
+                               (37, 104, 96, 21, -0.75, 3)])
+def test_fused_residual_and_gradient_steps(oracle, ops, g):
     P, H = make_pair(oracle, g)
     rng = np.random.default_rng(3)
     b = rng.random((P.nz, P.na, P.nu)).astype(np.float32)
@@ -388,6 +391,34 @@ def test_projector_pair_random_geometries(oracle, ops, seed):
             got = host(H.backward(dev(sino), s))
             assert np.array_equal(got, want_bp), ("bp", v, seed, s, (nz, n, nu, na, os_n))
         ops.set_variant("bp", 0)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_tv_large_odd_shapes(oracle, ops, seed):
+    """Large odd-shaped volumes (several z-chunks, hundreds of interior waves running the short form of the z-march
+    kernels next to edge waves running the general form, ragged edges in every direction): the shipped three-iteration
+    PD_TV tiling with exact roundings (variant 22 = what binary16 duals ship; 21 = compiler IEEE sequences) and the
+    shipped ROF_TV against the oracle, bit for bit; the shipped float32-dual PD_TV within 1e-5."""
+    from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
+    rng = np.random.default_rng(9100 + seed)
+    shape = (int(rng.integers(75, 230)), int(rng.integers(150, 420)), int(rng.integers(250, 700)))
+    x = (rng.random(shape) * 0.4 + (np.indices(shape)[-1] > shape[-1] // 3) - 0.3).astype(np.float32)
+    iters = int(rng.choice([3, 6, 7, 9]))
+    half, mtv, nn = bool(seed & 1), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    lam = float(rng.choice([0.01, 0.05]))
+    want = oracle.pd_tv(x, lam, iters, mtv, nn, 8.0, half)
+    xd = dev(x)
+    for v in ([22, 0] if half else [22, 21]):   # variant 0 with binary16 duals IS the exact build
+        ops.set_variant("pdtv", v)
+        got = host(PD_TV_cupy(xd, lam, iters, mtv, nn, 8.0, 0, half))
+        assert np.array_equal(got, want), ("pd", v, shape, iters, half, mtv, nn, np.abs(got - want).max())
+    ops.set_variant("pdtv", 0)
+    got = host(PD_TV_cupy(xd, lam, iters, mtv, nn, 8.0, 0, half))
+    assert rel(got, want) < 1e-5, ("pd shipped", shape, iters, half, mtv, nn, rel(got, want))
+    ops.set_variant("roftv", 0)
+    want_rof = oracle.rof_tv(x, lam, iters, 0.004, half)
+    got = host(ROF_TV_cupy(xd, lam, iters, 0.004, 0, half))
+    assert np.array_equal(got, want_rof), ("rof", shape, iters, half, np.abs(got - want_rof).max())
 
 
 @pytest.mark.parametrize("seed", range(16))
