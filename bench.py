@@ -242,6 +242,14 @@ def main():
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
 
+    # Several ranks: everything a library prints on stdout during the run (gloo announces its connections there: "[Gloo]
+    # Rank 1 is connected to 3 peer ranks ...") goes to stderr, so that the ONE JSON line of rank 0 is all stdout carries.
+    json_out = sys.stdout
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -480,7 +488,7 @@ def main():
             line["halo"] = halo
         if not args.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, sino, lc)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
