@@ -310,6 +310,31 @@ __global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(2)
                         for (int i = 0; i < NR; ++i) Pnext[s + 1][c][i] = Pw[c][i];
                 } else {
                     // swap through LDS: fetch what stage s+1 needs NOW (last step's hand-over), leave this step's behind
+                    if constexpr (sizeof(T) == 2) {
+                        // binary16 duals: what is handed over is the binary16 rounding of the dual anyway, so two of them
+                        // share one LDS word (even slot of a pair; half the ds operations, three conversions per pair
+                        // instead of four)
+                        constexpr int ROWS = xk_dual_rows(K, RY, s + 1), NV = 3 * ROWS, B0 = xk_p_base(K, RY, s + 1);
+#pragma unroll
+                        for (int m = 0; m < NV; ++m) {
+                            const int slot = B0 + m, c = m / ROWS, i = m % ROWS + (s + 1);
+                            const bool first = (slot % 2 == 0) && slot >= LREG && m + 1 < NV;
+                            const bool second = (slot % 2 == 1) && slot - 1 >= LREG && m >= 1;
+                            if (second) continue;
+                            if (first) {
+                                const int c1 = (m + 1) / ROWS, i1 = (m + 1) % ROWS + (s + 1);
+                                const float oldw = lag[slot - LREG][tid];
+                                lag[slot - LREG][tid] = pack_half2_twice_rounded(Pw[c][i], Pw[c1][i1]);
+                                unpack_half2(oldw, Pw[c][i], Pw[c1][i1]);
+                            } else {
+                                const float nxt = Pw[c][i];
+                                float old;
+                                if (slot < LREG) { old = lagreg[slot]; lagreg[slot] = nxt; }
+                                else { old = lag[slot - LREG][tid]; lag[slot - LREG][tid] = nxt; }
+                                Pw[c][i] = DualIO<T>::rt(old);
+                            }
+                        }
+                    } else
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
 #pragma unroll

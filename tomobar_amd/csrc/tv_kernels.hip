@@ -53,6 +53,22 @@ __device__ __forceinline__ __half f32_to_half_twice_rounded(float v)
     asm volatile("" : "+v"(v));
     return __float2half_rn(v);
 }
+// two such conversions in one v_cvt_pk_f16_f32 (the pair travels as one 32-bit word), and back
+typedef float tv_v2f32 __attribute__((ext_vector_type(2)));
+typedef _Float16 tv_v2f16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float pack_half2_twice_rounded(float a, float b)
+{
+    asm volatile("" : "+v"(a), "+v"(b));
+    const tv_v2f32 v = {a, b};
+    const tv_v2f16 h = __builtin_convertvector(v, tv_v2f16);
+    return __builtin_bit_cast(float, h);
+}
+__device__ __forceinline__ void unpack_half2(float w, float &a, float &b)
+{
+    const tv_v2f32 v = __builtin_convertvector(__builtin_bit_cast(tv_v2f16, w), tv_v2f32);
+    const float x = v.x, y = v.y;
+    a = x; b = y;
+}
 template <> struct DualIO<__half> {
     static __device__ __forceinline__ float ld(const __half *p, size_t i) { return __half2float(p[i]); }
     static __device__ __forceinline__ void st(__half *p, size_t i, float v) { p[i] = f32_to_half_twice_rounded(v); }
