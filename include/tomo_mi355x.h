@@ -317,9 +317,10 @@ int tomo_fourier_inv(int device, const float *data_dev, float *out_dev, int nz, 
                      int m, float mu, int center_size, void *stream);
 
 /* kernel-variant selector (per calling host thread): name in {"bp","fp","pdtv","roftv"}; variant 0 = shipped default.
- * The ones a user may care about: "pdtv" 2 = the build that reproduces the reference kernels' rounding sequence bit for
- * bit (IEEE sqrt / divide; the shipped float32-dual build uses v_rsq / a hoisted reciprocal and stays within 1e-5 of it),
- * 3 = relaxed arithmetic for binary16 duals as well.  "roftv" 0 already reproduces the reference's roundings (FMA-corrected
+ * The ones a user may care about: "pdtv" 22 = the shipped three-iteration kernel with the reference kernels' rounding
+ * sequence reproduced bit for bit (FMA-corrected 1/sqrt and quotient, +4..7 %; what binary16 duals ship anyway -- the
+ * shipped float32-dual build uses v_rsq / a hoisted reciprocal and stays within 1e-5 of it), 2 = the same roundings through
+ * the compiler's IEEE sqrt / divide on the two-iteration kernel, 3 = relaxed arithmetic for binary16 duals as well.  "roftv" 0 already reproduces the reference's roundings (FMA-corrected
  * sqrt / divide); 3 = relaxed arithmetic (30 % faster, can leave the 1e-5 band on noise-dominated data).  Everything else
  * ("probe" included) is A/B measurement. */
 int tomo_set_variant(const char *kernel, int variant);
