@@ -16,6 +16,13 @@
 // back exactly where it is consumed.  That is what lets K = 3 run with RY = 4 rows at two waves per SIMD (46 values per
 // lane would otherwise push the kernel past 256 registers): 45 row loads / 21 dual rows per 12 output-row-iterations
 // instead of 40 / 18 per 9.
+// Shipped instantiation (round 3): K = 3, RY = 8 rows per lane, 2 x 2 waves, LAG with 10 slots in registers -- 33 dual-row
+// evaluations and 65 row loads per 24 output-row-iterations; float32 duals with relaxed arithmetic (FAST = 1), binary16
+// duals with the reference's roundings (FAST = 2).
+// Two forms of a step (`EDGE` below): the general one with every boundary select and activity test, and a SHORT one for
+// waves whose lanes and row slots lie strictly inside the slice, on planes where every stage is active and none sits on
+// the first / last plane: same operands, no selects (760 instead of 1480 VALU instructions per step).  The march runs
+// them in separate loops: [general | short | general].
 // compile-time stage loop: `s` must be a constant inside the stage body.  With a run-time (unrolled) loop the code of
 // "s + 1 < K" for the last stage survives as a dead, not yet unrolled loop with variable indices into the register
 // arrays until after the last scalar-replacement pass, which then leaves the arrays in scratch memory.
