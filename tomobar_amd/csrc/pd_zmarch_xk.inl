@@ -258,6 +258,10 @@ __global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(2)
                 // ---------------- primal, rows -(K-s-1) .. RY+(K-s-1)-1, four rows at a time
                 const bool emit_plane = (s == K - 1) && (!EDGE || p >= zc0);
                 constexpr int Q0 = -(K - s - 1), Q1 = RY + (K - s - 1) - 1;
+                // output descriptors of this plane, built once (last stage only)
+                const size_t po = sz * ((a.probe & 4) ? 0 : (s == K - 1 ? p : 0));
+                const __amdgpu_buffer_rsrc_t r_uo = io.rsf(a.u_out + po);
+                const __amdgpu_buffer_rsrc_t r_p0 = io.rsd(P_out[0] + po), r_p1 = io.rsd(P_out[1] + po), r_p2 = io.rsd(P_out[2] + po);
 #pragma unroll
                 for (int rb = Q0; rb <= Q1; rb += DB) {
                     float uu[DB], in4[DB], dv[DB], uo[DB];
@@ -284,10 +288,11 @@ __global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(2)
                             Vn[i] = uo[k];
                             if constexpr (s == K - 1) {
                                 if (emit_plane && emit_lane && (!EDGE || y < dy)) {
-                                    io.stf(a.u_out + sz * ((a.probe & 4) ? 0 : p), xo, rowoff(i, ec), uo[k]);
+                                    PlaneIO::stf_rs(r_uo, xo, rowoff(i, ec), uo[k]);
                                     if (!a.p_out_skip) {  // uniform: nobody reads the duals of the last launch of a prox
-#pragma unroll
-                                        for (int c = 0; c < 3; ++c) io.std_(P_out[c] + sz * ((a.probe & 4) ? 0 : p), xo, rowoff(i, ec), Pw[c][i]);
+                                        PlaneIO::std_rs(P_out[0], r_p0, xo, rowoff(i, ec), Pw[0][i]);
+                                        PlaneIO::std_rs(P_out[1], r_p1, xo, rowoff(i, ec), Pw[1][i]);
+                                        PlaneIO::std_rs(P_out[2], r_p2, xo, rowoff(i, ec), Pw[2][i]);
                                     }
                                 }
                             }

@@ -120,6 +120,20 @@ struct PlaneIO {
         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, f32_to_half_twice_rounded(v)), rs(plane, bytes >> 1),
                                               (int)(xo >> 1), ro >> 1, 0);
     }
+    // stores through a descriptor built once per plane (a store inside a guarded row loop otherwise rebuilds it: three
+    // scalar instructions per store)
+    __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsf(const float *plane) const { return rs(plane, bytes); }
+    __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsd(const float *plane) const { return rs(plane, bytes); }
+    __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsd(const __half *plane) const { return rs(plane, bytes >> 1); }
+    static __device__ __forceinline__ void stf_rs(__amdgpu_buffer_rsrc_t r, unsigned xo, int ro, float v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)xo, ro, 0);
+    }
+    static __device__ __forceinline__ void std_rs(const float *, __amdgpu_buffer_rsrc_t r, unsigned xo, int ro, float v) { stf_rs(r, xo, ro, v); }
+    static __device__ __forceinline__ void std_rs(const __half *, __amdgpu_buffer_rsrc_t r, unsigned xo, int ro, float v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, f32_to_half_twice_rounded(v)), r, (int)(xo >> 1), ro >> 1, 0);
+    }
     // dual fields: float or binary16 (boff is always the FLOAT byte offset of the voxel)
     __device__ __forceinline__ float ldd(const float *plane, unsigned boff) const { return ldf(plane, boff); }
     __device__ __forceinline__ void std_(float *plane, unsigned boff, float v) const { stf(plane, boff, v); }
