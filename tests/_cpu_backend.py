@@ -144,20 +144,9 @@ def install(monkeypatch=None):
     import tomobar_amd.supp.dicts as DI
     import tomobar_amd.supp.suppTools as ST
     ops = make_ops()
-    def halo_pack(tensors, nbytes, staging):
-        off = 0
-        for t, nb in zip(tensors, nbytes):
-            staging[off:off + nb] = t.reshape(-1).view(torch.uint8)
-            off += (nb + 15) // 16 * 16
-
-    def halo_unpack(staging, tensors, nbytes):
-        off = 0
-        for t, nb in zip(tensors, nbytes):
-            t.reshape(-1).view(torch.uint8)[:] = staging[off:off + nb]
-            off += (nb + 15) // 16 * 16
-
-    sets = [(SL, "_hip_halo_pack", halo_pack), (SL, "_hip_halo_unpack", halo_unpack),
-            (SL, "_hip_pd_kmax", lambda half: 3), (IR, "ops", ops), (IR, "HipTools3D", OracleTools3D), (REG, "ops", ops), (DI, "ops", ops), (ST, "ops", ops),
+    # host tensors never reach tomo_halo_pack / tomo_halo_unpack / tomo_pdtv_iters_per_launch: slab.py packs them with
+    # plain copies and plans three iterations per launch without a GPU (round 4) -- no stand-in needed for those
+    sets = [(IR, "ops", ops), (IR, "HipTools3D", OracleTools3D), (REG, "ops", ops), (DI, "ops", ops), (ST, "ops", ops),
             (SL, "_hip_pd_pair", O.pd_pair_slab), (SL, "_hip_pd_step", O.pd_step_slab), (SL, "_hip_rof_step", O.rof_step_slab)]
     for mod, name, val in sets:
         if monkeypatch is not None:

@@ -85,6 +85,63 @@ def test_full_size_tv_shipped_arithmetic(oracle):
         del got3
 
 
+# ---- full-size TV on a z-VARYING volume (round 4).  The z-invariant tests above never exercise the z carry, the seams
+# between z-chunks or the [general | short | general] split of the march with non-zero z-differences.  One PD_TV / ROF_TV
+# iteration moves information by at most one plane (PD: U(z) <- P(z), P(z-1) <- U(z-1..z+1); ROF: U(z) <- D(z), D(z-1) <-
+# U(z-2..z+1), counted as two), so the oracle run on a 40-plane slab of the input equals the whole-volume result on the
+# planes whose dependency cone stays inside the slab -- or ends at a true volume face, where the slab's boundary rule IS
+# the volume's.  Three slabs: bottom face, the z-chunk seam at plane 512 (32 chunks of 32 planes), top face.
+_CONE_SLAB = 40
+
+
+def _cone_cases(nz, reach):
+    """(slab begin, slab end, first valid plane, one past the last valid plane) for `reach` planes of dependency."""
+    mid = nz // 2 - _CONE_SLAB // 2
+    return [(0, _CONE_SLAB, 0, _CONE_SLAB - reach),
+            (mid, mid + _CONE_SLAB, mid + reach, mid + _CONE_SLAB - reach),
+            (nz - _CONE_SLAB, nz, nz - _CONE_SLAB + reach, nz)]
+
+
+def _z_varying_volume(nz, dy, dx):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    vol = torch.rand((nz, dy, dx), generator=g, device="cuda") * 0.3
+    # piecewise-constant structure that moves with z (saturated duals on the faces, in all three directions)
+    zz = torch.arange(nz, device="cuda").view(nz, 1, 1)
+    yy = torch.arange(dy, device="cuda").view(1, dy, 1)
+    xx = torch.arange(dx, device="cuda").view(1, 1, dx)
+    vol += ((xx + 2 * zz) % 97 > 48).float() + 0.5 * ((yy + 3 * zz) % 61 > 30).float() + 0.25 * ((zz % 9) > 4).float()
+    return vol
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_full_size_pdtv_z_varying_cone(oracle, half):
+    from tomobar_amd.regularisersCuPy import PD_TV_cupy
+    nz, dy, dx, iters = 1024, 1024, 1024, 6
+    vol = _z_varying_volume(nz, dy, dx)
+    got = PD_TV_cupy(vol, 0.04, iters, 0, 1, 12.0, 0, half)
+    for z0, z1, v0, v1 in _cone_cases(nz, iters):
+        want = oracle.pd_tv(vol[z0:z1].cpu().numpy(), 0.04, iters, 0, 1, 12.0, half)
+        w = torch.from_numpy(want[v0 - z0:v1 - z0]).cuda()
+        assert v1 - v0 >= 16
+        assert torch.equal(got[v0:v1], w), (z0, float((got[v0:v1] - w).abs().max()))
+        # the cone argument itself: one plane further the slab's artificial boundary has arrived (interior slabs only)
+        if z0 > 0:
+            assert not np.array_equal(want[v0 - z0 - 1], got[v0 - 1].cpu().numpy())
+
+
+def test_full_size_roftv_z_varying_cone(oracle):
+    from tomobar_amd.regularisersCuPy import ROF_TV_cupy
+    nz, dy, dx, iters = 1024, 1024, 1024, 6
+    vol = _z_varying_volume(nz, dy, dx)
+    got = ROF_TV_cupy(vol, 0.04, iters, 0.005, 0, False)
+    for z0, z1, v0, v1 in _cone_cases(nz, 2 * iters):
+        want = oracle.rof_tv(vol[z0:z1].cpu().numpy(), 0.04, iters, 0.005, False)
+        w = torch.from_numpy(want[v0 - z0:v1 - z0]).cuda()
+        assert v1 - v0 >= 16
+        assert torch.equal(got[v0:v1], w), (z0, float((got[v0:v1] - w).abs().max()))
+
+
 def test_config3_shape_projector_pair_against_oracle(oracle):
     """BASELINE configs[3] geometry (2048^2 slices, 1500 angles, no subsets; a 70-slice piece of a GPU's z-slab): same
     power-of-two slice scaling argument.  Exercises the two-tile detector, windows wider than 1024 columns and a ragged

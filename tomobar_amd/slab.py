@@ -75,7 +75,7 @@ class SlabComm:
         self.has_hi = self.rank < self.world - 1
         self.backend = dist.get_backend(group) if dist.is_initialized() else "gloo"
         self.staged = self.backend != "nccl"   # tensors handed to the backend must live on the host
-        self._stage_bufs = {}
+        self._stage_free = []   # packed-halo staging buffers not owned by an exchange in flight (see _take_staging)
         self._events = []
         self._wait_stream_ms = 0.0
         self.timing = False   # bench.py switches the HIP-event timing of the waits on
@@ -118,12 +118,17 @@ class SlabComm:
                              f"3D TV needs {min_slices}-plane ghosts; use fewer ranks or balance the split with slab_bounds()")
 
     # ---- halo exchange
-    def _staging(self, key, nbytes, device):
-        buf = self._stage_bufs.get(key)
-        if buf is None or buf.numel() < nbytes or buf.device != device:
-            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-            self._stage_bufs[key] = buf
-        return buf[:int(nbytes)]
+    def _take_staging(self, nbytes, device):
+        """A staging buffer owned by ONE exchange from its post to the end of its wait(): exchange_start / exchange_wait
+        allow several exchanges in flight, and a second post must neither pack into nor receive into a buffer an
+        outstanding transfer still uses.  Buffers return to the pool in _Exchange.wait()."""
+        nbytes = int(nbytes)
+        best = None
+        for i, buf in enumerate(self._stage_free):
+            if buf.device == device and buf.numel() >= nbytes and (best is None or buf.numel() < self._stage_free[best].numel()):
+                best = i
+        buf = self._stage_free.pop(best) if best is not None else torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return buf
 
     def _post(self, send_down, recv_down, send_up, recv_up):
         """One exchange = at most ONE send and ONE receive per neighbour: the blocks of a direction (U, P1, P2, P3 planes,
@@ -131,7 +136,7 @@ class SlabComm:
         arrival (tomo_halo_unpack).  Returns a handle whose wait() completes the transfers and the scatter."""
         t_host = time.perf_counter()
         P2POp = self.dist.P2POp
-        plan, unpack = [], []
+        plan, unpack, owned = [], [], []
         for name, tensors, peer, fn in (("sd", send_down, self.rank - 1, self.dist.isend),
                                         ("rd", recv_down, self.rank - 1, self.dist.irecv),
                                         ("su", send_up, self.rank + 1, self.dist.isend),
@@ -142,16 +147,19 @@ class SlabComm:
                 if not t.is_contiguous():
                     raise ValueError("halo blocks must be contiguous plane ranges")
             nbytes = [t.numel() * t.element_size() for t in tensors]
-            stage = self._staging(name, _halo_staging_bytes(nbytes), tensors[0].device)
+            need = _halo_staging_bytes(nbytes)
+            buf = self._take_staging(need, tensors[0].device)
+            owned.append(buf)
+            stage = buf[:need]
             if fn is self.dist.isend:
-                _hip_halo_pack(tensors, nbytes, stage)
+                _halo_pack(tensors, nbytes, stage)
             else:
                 unpack.append((stage, tensors, nbytes))
             plan.append((fn, stage, peer))
             self.stats["messages"] += 1
             self.stats["bytes"] += int(sum(nbytes)) if fn is self.dist.isend else 0
         if not plan:
-            return _Exchange(self, [], [], None)
+            return _Exchange(self, [], [], None, [])
         if not (self.staged and any(t.is_cuda for _, t, _ in plan)):
             reqs = list(self.dist.batch_isend_irecv([P2POp(fn, t, peer, self.group) for fn, t, peer in plan]))
         else:
@@ -165,7 +173,7 @@ class SlabComm:
             reqs = [_StagedRequest(r, h, d) for r, (h, d) in zip(self.dist.batch_isend_irecv(ops), hosts)]
         self.stats["exchanges"] += 1
         self.stats["post_host_ms"] += (time.perf_counter() - t_host) * 1e3
-        return _Exchange(self, reqs, unpack, plan[0][1].device)
+        return _Exchange(self, reqs, unpack, plan[0][1].device, owned)
 
     def exchange(self, send_down: List[torch.Tensor], recv_down: List[torch.Tensor],
                  send_up: List[torch.Tensor], recv_up: List[torch.Tensor]):
@@ -203,8 +211,8 @@ class SlabComm:
 class _Exchange:
     """Handle of one packed halo exchange: wait() completes the requests and scatters what arrived."""
 
-    def __init__(self, comm, reqs, unpack, device):
-        self.comm, self.reqs, self.unpack, self.device = comm, reqs, unpack, device
+    def __init__(self, comm, reqs, unpack, device, owned):
+        self.comm, self.reqs, self.unpack, self.device, self.owned = comm, reqs, unpack, device, owned
 
     def wait(self):
         comm = self.comm
@@ -216,18 +224,42 @@ class _Exchange:
         for req in self.reqs:
             req.wait()
         for stage, tensors, nbytes in self.unpack:
-            _hip_halo_unpack(stage, tensors, nbytes)
+            _halo_unpack(stage, tensors, nbytes)
         if on_gpu:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(torch.cuda.current_stream(self.device))
             comm._events.append((e0, e1))
         comm.stats["wait_host_ms"] += (time.perf_counter() - t_host) * 1e3
-        self.reqs, self.unpack = [], []
+        # the staging buffers go back to the pool: on the GPU every later use is ordered after the scatter on the same stream
+        comm._stage_free.extend(self.owned)
+        self.reqs, self.unpack, self.owned = [], [], []
 
 
 def _halo_staging_bytes(nbytes):
     """tomo_halo_staging_bytes: every block starts 16-byte aligned in the staging buffer."""
     return sum((int(b) + 15) // 16 * 16 for b in nbytes)
+
+
+def _halo_pack(tensors, nbytes, staging):
+    """Device blocks: tomo_halo_pack (one kernel).  Host blocks (a SlabComm driven with CPU tensors over gloo, e.g. with
+    custom step functions): plain slice copies -- the library only ever sees device pointers."""
+    if staging.device.type != "cuda":
+        off = 0
+        for t, b in zip(tensors, nbytes):
+            staging[off:off + int(b)].copy_(t.reshape(-1).view(torch.uint8))
+            off += (int(b) + 15) // 16 * 16
+        return
+    _hip_halo_pack(tensors, nbytes, staging)
+
+
+def _halo_unpack(staging, tensors, nbytes):
+    if staging.device.type != "cuda":
+        off = 0
+        for t, b in zip(tensors, nbytes):
+            t.reshape(-1).view(torch.uint8).copy_(staging[off:off + int(b)])
+            off += (int(b) + 15) // 16 * 16
+        return
+    _hip_halo_unpack(staging, tensors, nbytes)
 
 
 def _hip_halo_pack(tensors, nbytes, staging):
@@ -252,6 +284,8 @@ def _hip_halo_unpack(staging, tensors, nbytes):
 
 def _hip_pd_kmax(half: bool) -> int:
     """PD_TV iterations per fused launch, asked of the library (csrc/tv_kernels.hip: pd_iters_per_launch)."""
+    if not torch.cuda.is_available():
+        return 3   # host tensors (gloo functional path): the plan of the shipped kernels, three iterations per launch
     from . import _lib as L
     return int(L.lib().tomo_pdtv_iters_per_launch(int(bool(half))))
 
