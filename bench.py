@@ -105,6 +105,9 @@ def parse():
     p.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     p.add_argument("--cpu-slices", type=int, default=8)
+    p.add_argument("--relaxed-tv", action="store_true",
+                   help="PD_TV with the opt-in relaxed arithmetic (tomo_set_variant('pdtv', 3): <= 1e-5 from the default, "
+                        "which reproduces the reference's roundings); the workload string says so")
     p.add_argument("--no-north-star", action="store_true",
                    help="N > 1 only: skip the extra `north_star` block (strong scaling of configs[4] when it fits)")
     if len(sys.argv) == 1 and "TOMO_BENCH_ARGV" in os.environ and "RANK" in os.environ:  # rank started by self_launch()
@@ -135,6 +138,8 @@ def apply_preset(args):
             overridden.append(key)
     if args.half:
         overridden.append("half")
+    if getattr(args, "relaxed_tv", False):
+        overridden.append("relaxed PD_TV arithmetic")
     args.overridden = overridden   # the workload string names the BASELINE config only when nothing was overridden
 
 
@@ -274,6 +279,7 @@ def measure(args, env):
     from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
     from tomobar_amd.slab import GHOST, SlabComm, check_slab_split, pd_launch_plan, slab_bounds
     lib = _lib.lib()
+    lib.tomo_set_variant(b"pdtv", 3 if getattr(args, "relaxed_tv", False) else 0)
 
     n, na = args.n, args.angles
     if args.strong:

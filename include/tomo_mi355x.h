@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* raised whenever an entry point is added or a signature changes (tomobar_amd/_lib.py checks it at load) */
-#define TOMO_ABI_VERSION 2
+#define TOMO_ABI_VERSION 3
 
 enum {
     TOMO_OK = 0,
@@ -59,6 +59,8 @@ typedef struct {
 } tomo_angle_t;
 
 int tomo_abi_version(void);
+/* "shipped" (libtomo_mi355x.so) or "dev" (libtomo_mi355x_dev.so, built with -DTOMO_DEV_VARIANTS for tests / tools) */
+const char *tomo_build_flavour(void);
 const char *tomo_last_error(void);
 int tomo_device_count(int *count);
 
@@ -316,13 +318,13 @@ int tomo_fourier_inv(int device, const float *data_dev, float *out_dev, int nz, 
                      int n, int ne, int unpad_m, int out_size, const float *w_host, const float *theta_host,
                      int m, float mu, int center_size, void *stream);
 
-/* kernel-variant selector (per calling host thread): name in {"bp","fp","pdtv","roftv"}; variant 0 = shipped default.
- * The ones a user may care about: "pdtv" 22 = the shipped three-iteration kernel with the reference kernels' rounding
- * sequence reproduced bit for bit (FMA-corrected 1/sqrt and quotient, +4..7 %; what binary16 duals ship anyway -- the
- * shipped float32-dual build uses v_rsq / a hoisted reciprocal and stays within 1e-5 of it), 2 = the same roundings through
- * the compiler's IEEE sqrt / divide on the two-iteration kernel, 3 = relaxed arithmetic for binary16 duals as well.  "roftv" 0 already reproduces the reference's roundings (FMA-corrected
- * sqrt / divide); 3 = relaxed arithmetic (30 % faster, can leave the 1e-5 band on noise-dominated data).  Everything else
- * ("probe" included) is A/B measurement. */
+/* kernel-variant selector (per calling host thread): name in {"bp","fp","pdtv","roftv"}; variant 0 = the default of every
+ * class.  The shipped library accepts exactly one other value: "pdtv" 3 = relaxed arithmetic (v_rsq_f32 instead of
+ * 1 / sqrtf, a host-computed 1 / (1 + lt) instead of the divide; within 1e-5 of the default on float32 duals, 1-2 % faster)
+ * -- the default reproduces the rounding sequence of the reference's kernels (primal_dual_for_total_variation.cu:66-123,
+ * rudin_osher_fatemi_total_variation.cu:51-61) bit for bit, for float32 and binary16 duals.  Anything else returns
+ * TOMO_E_INVALID: the independent implementations and A/B builds used by tests/ and tools/ (bp 1/2, fp 1/2, pdtv 1/2/21,
+ * roftv 1..4) and the measurement switches ("probe") exist only in libtomo_mi355x_dev.so (csrc/Makefile: `make dev`). */
 int tomo_set_variant(const char *kernel, int variant);
 
 /* In-library kernel timing for bench.py's roofline object: while enabled, every launch group of a kernel class

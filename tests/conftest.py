@@ -10,28 +10,30 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "default_arithmetic: run the TV operators as shipped (relaxed arithmetic: v_rsq / "
-                                       "v_rcp, hoisted reciprocal) instead of the exact-rounding variants")
+    config.addinivalue_line("markers", "dev_variants: runs with the package pointed at libtomo_mi355x_dev.so, the build that "
+                                       "also carries the independent kernel implementations / A-B variants")
 
 
 @pytest.fixture(autouse=True)
-def _tv_arithmetic(request):
-    """The shipped PD_TV kernels use relaxed arithmetic for float32 duals (<= 1e-6 from the oracle per call; variant 0).
-    Bit-for-bit comparisons with the oracle need exact roundings: every GPU test gets variant 22 -- the SHIPPED
-    three-iteration kernel and tiling with the FMA-corrected roundings (what binary16 duals ship) -- unless it is marked
-    ``default_arithmetic`` (those tests check the shipped float32 path against the north-star tolerance).  The other
-    exact builds (2: two-iteration kernel with the compiler's IEEE sequences, 21, 1) are parametrised explicitly in
-    test_gpu_parity.py.  ROF_TV ships the reference's own roundings since round 3 and always runs as shipped."""
+def _library_flavour(request):
+    """GPU tests run the SHIPPED library (tomobar_amd/libtomo_mi355x.so) with every kernel class at its default -- since
+    round 4 the defaults reproduce the oracle's roundings, so bit-for-bit comparisons need no variant switch.  A test (or
+    parameter) marked ``dev_variants`` compares another implementation of a kernel: for its duration the package is
+    pointed at libtomo_mi355x_dev.so (same sources + -DTOMO_DEV_VARIANTS).  Variant switches are per library and are
+    reset after every test."""
     if request.node.get_closest_marker("gpu") is None:
         yield
         return
-    from tomobar_amd import ops
-    exact = request.node.get_closest_marker("default_arithmetic") is None
-    ops.set_variant("pdtv", 22 if exact else 0)
-    ops.set_variant("roftv", 0)   # the shipped ROF_TV reproduces the reference's roundings (round 3): no switch needed
-    yield
-    for k in ("bp", "fp", "pdtv", "roftv"):
-        ops.set_variant(k, 0)
+    from tomobar_amd import _lib, ops
+    dev = request.node.get_closest_marker("dev_variants") is not None
+    ctx = _lib.use_flavour("dev") if dev else None
+    try:
+        yield
+    finally:
+        for k in ("bp", "fp", "pdtv", "roftv"):
+            ops.set_variant(k, 0)
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
 
 
 @pytest.fixture(scope="session")

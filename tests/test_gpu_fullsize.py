@@ -68,10 +68,12 @@ def test_full_size_tv_on_z_invariant_volume(oracle, shape):
     assert torch.equal(got3, want2.view(1, dy, dx).expand_as(got3)), float((got3 - want2.view(1, dy, dx)).abs().max())
 
 
-@pytest.mark.default_arithmetic
-def test_full_size_tv_shipped_arithmetic(oracle):
-    """1024^3 with the TV kernels as shipped (relaxed arithmetic): the z-invariance property within the tolerance."""
+def test_full_size_tv_30_iterations_and_relaxed_pdtv(oracle):
+    """1024^3, 30 iterations: the z-invariance property with the opt-in relaxed PD_TV arithmetic (variant 3) within the
+    north-star tolerance, and with the shipped ROF_TV."""
+    from tomobar_amd import ops
     from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
+    ops.set_variant("pdtv", 3)
     nz, dy, dx = 1024, 1024, 1024
     rng = np.random.default_rng(1)
     base = (rng.random((dy, dx), dtype=np.float32) * 0.3 + (np.indices((dy, dx))[1] > dx // 2)).astype(np.float32)
@@ -222,12 +224,14 @@ def test_config5_shape_per_gpu(oracle):
     assert torch.equal(got3, want2.view(1, n, n).expand_as(got3))
 
 
-def test_bench_geometry_end_to_end_against_oracle(oracle, shipped=False):
+def test_bench_geometry_end_to_end_against_oracle(oracle, relaxed=False):
     """The bench workload's own geometry (1024-wide detector, 900 angles in 12 subsets, FISTA-OS + PD_TV) on an 8-slice
     volume, one outer iteration = 12 sub-iterations: the kernels the bench runs (whole-row forward projector, brick
     back projector with the FISTA epilogue, three-iteration PD_TV, momentum) in the real loop, against the CPU oracle's
-    run of the same loop -- bit for bit with the exact-rounding TV builds (the conftest default for GPU tests)."""
+    run of the same loop -- bit for bit, as shipped."""
+    from tomobar_amd import ops
     from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    ops.set_variant("pdtv", 3 if relaxed else 0)
     n, nz, na, os_n = 1024, 8, 900, 12
     angles = np.linspace(0, np.pi, na, endpoint=False)
     P = oracle.Projector(nz, n, n, angles, 0.0, os_n)
@@ -245,18 +249,17 @@ def test_bench_geometry_end_to_end_against_oracle(oracle, shipped=False):
     assert "brick" in rt.Atools.kernel_path("bp"), rt.Atools.kernel_path("bp")
     torch.cuda.synchronize()
     g = got.cpu().numpy()
-    if shipped:
+    if relaxed:
         err = float(np.linalg.norm((g - want).astype(np.float64)) / np.linalg.norm(want.astype(np.float64)))
-        print("bench geometry, shipped TV arithmetic: rel-L2 vs oracle =", err)
+        print("bench geometry, relaxed PD_TV arithmetic: rel-L2 vs oracle =", err)
         assert err < 1e-5, err
     else:
         assert np.array_equal(g, want), float(np.abs(g - want).max())
 
 
-@pytest.mark.default_arithmetic
-def test_bench_geometry_end_to_end_shipped_arithmetic(oracle):
-    """The same run with the TV kernels as shipped (relaxed arithmetic): within the north-star tolerance."""
-    test_bench_geometry_end_to_end_against_oracle(oracle, shipped=True)
+def test_bench_geometry_end_to_end_relaxed_pdtv(oracle):
+    """The same run with the opt-in relaxed PD_TV arithmetic (variant 3): within the north-star tolerance."""
+    test_bench_geometry_end_to_end_against_oracle(oracle, relaxed=True)
 
 
 def test_config3_geometry_admm_rof_end_to_end_against_oracle(oracle):

@@ -10,6 +10,14 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
+# kernel variants other than the defaults live in libtomo_mi355x_dev.so: a parameter / test marked `dev_variants` runs with the
+# package pointed at that library (tests/conftest.py); everything else runs the shipped libtomo_mi355x.so
+DEV = pytest.mark.dev_variants
+
+
+def _v(*variants):
+    return [v if v == 0 else pytest.param(v, marks=DEV) for v in variants]
+
 
 
 def rel(a, b):
@@ -58,7 +66,7 @@ def make_pair(oracle, g, flags=0):
 
 
 @pytest.mark.parametrize("g", GEOMS)
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", _v(0, 1, 2))
 def test_backprojection_vs_oracle(oracle, ops, g, variant):
     P, H = make_pair(oracle, g)
     ops.set_variant("bp", variant)
@@ -75,7 +83,7 @@ def test_backprojection_vs_oracle(oracle, ops, g, variant):
 
 
 @pytest.mark.parametrize("g", GEOMS + [(4, 300, 520, 40, 3.0, 1), (5, 64, 700, 13, 0.0, 1)])
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", _v(0, 1, 2))
 def test_forward_projection_vs_oracle(oracle, ops, g, variant):
     P, H = make_pair(oracle, g)
     ops.set_variant("fp", variant)
@@ -91,7 +99,7 @@ def test_forward_projection_vs_oracle(oracle, ops, g, variant):
 
 
 @pytest.mark.parametrize("n,na,os_n", [(280, 180, 5), (256, 180, None), (300, 60, None), (280, 90, 3)])
-@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("variant", _v(0, 2))
 def test_forward_projection_oblique_windows(oracle, ops, n, na, os_n, variant):
     """Regression: detector tiles whose staged row window is clipped by the volume at both ends of the march but not
     in the middle (oblique rays at the detector edge) -- the LDS pitch must come from the unclipped window."""
@@ -106,7 +114,8 @@ def test_forward_projection_oblique_windows(oracle, ops, n, na, os_n, variant):
         assert np.array_equal(got, P.fp(vol, s)), (n, na, s)
 
 
-def test_lerp8_mode_and_reference_literals(oracle, ops):
+@pytest.mark.parametrize("bp_variants", [(0,), pytest.param((1, 2), marks=DEV)])
+def test_lerp8_mode_and_reference_literals(oracle, ops, bp_variants):
     """tests/test_RecToolsDIRCuPy.py:671-694 of the reference: ones(128,160,160) -> min 67.27458 max 225.27428."""
     from tomobar_amd.projector import HipTools3D
     angles = np.deg2rad(np.arange(180.0))
@@ -116,7 +125,7 @@ def test_lerp8_mode_and_reference_literals(oracle, ops):
     np.testing.assert_allclose(s.max(), 225.27428, rtol=2e-6)
     P = oracle.Projector(8, 160, 160, angles, flags=oracle.FLAG_LERP8)
     sino = np.random.default_rng(0).random((8, 180, 160)).astype(np.float32)
-    for v in (0, 1, 2):
+    for v in bp_variants:
         ops.set_variant("bp", v)
         assert rel(host(H.backward(dev(sino))), P.bp(sino)) < 1e-6
 
@@ -136,7 +145,8 @@ def test_power_method_literals(oracle):
                                # 3 x 6 x 2 whole 32x16x16 bricks (epilogue through LDS in dwordx4 row segments) next to
                                # ragged ones in x, y and z (direct stores) in the same launch
                                (37, 104, 96, 21, -0.75, 3)])
-def test_fused_residual_and_gradient_steps(oracle, ops, g):
+@pytest.mark.parametrize("bp_variants", [(0,), pytest.param((1, 2), marks=DEV)])
+def test_fused_residual_and_gradient_steps(oracle, ops, g, bp_variants):
     P, H = make_pair(oracle, g)
     rng = np.random.default_rng(3)
     b = rng.random((P.nz, P.na, P.nu)).astype(np.float32)
@@ -158,7 +168,7 @@ def test_fused_residual_and_gradient_steps(oracle, ops, g):
         r = (ax - b[:, idx]).astype(np.float32)
         grad = P.bp(r, s)
         linv, beta = np.float32(1 / 300.0), np.float32(0.37)
-        for variant in (0, 1, 2):
+        for variant in bp_variants:
             ops.set_variant("bp", variant)
             for nonneg in (False, True):
                 X = x - linv * grad
@@ -189,7 +199,9 @@ def test_fused_residual_and_gradient_steps(oracle, ops, g):
 
 # ------------------------------------------------------------------------------------------ TV operators
 TV_SHAPES = [(6, 9, 13), (1, 20, 17), (12, 1, 70), (10, 11, 1), (8, 8, 8), (3, 5, 131), (24, 19), (20, 70, 150)]
-PD_EXACT_VARIANTS = [2, 1, 21, 22]   # bit-identical to the oracle (22: FMA-corrected roundings); 0 (default f32), 3: relaxed arithmetic (tolerance)
+# bit-identical to the oracle: 0 = shipped (FMA-corrected roundings, both dual types); dev flavour: 2 / 21 = the compiler's IEEE
+# sequences on the two- / three-iteration kernel, 1 = per-voxel kernel.  3 = relaxed arithmetic (shipped, opt-in; tolerance)
+PD_EXACT_VARIANTS = _v(0, 2, 1, 21)
 
 
 @pytest.mark.parametrize("shape", TV_SHAPES)
@@ -211,10 +223,11 @@ def test_pdtv_vs_oracle(oracle, ops, shape, variant):
 
 
 @pytest.mark.parametrize("shape", [(9, 40, 70), (20, 70, 150), (5, 33, 131)])
-@pytest.mark.parametrize("variant", [0, 3])
+@pytest.mark.parametrize("variant", [3])
 def test_pdtv_relaxed_arithmetic_vs_oracle(oracle, ops, shape, variant):
-    """The relaxed-arithmetic builds (the shipped default and the tile kernel: v_rsq / v_rcp, hoisted 1/(1+lt)) stay
-    within the north-star tolerance of the oracle after 60 iterations."""
+    """The opt-in relaxed-arithmetic build of the shipped library (tomo_set_variant("pdtv", 3): v_rsq_f32, hoisted
+    1/(1+lt)) stays within the north-star tolerance of the oracle after 60 iterations (float32 duals; one flipped
+    binary16 rounding is 5e-4 of a dual value, so binary16 duals get 2e-4)."""
     from tomobar_amd.regularisersCuPy import PD_TV_cupy
     ops.set_variant("pdtv", variant)
     rng = np.random.default_rng(6)
@@ -223,12 +236,9 @@ def test_pdtv_relaxed_arithmetic_vs_oracle(oracle, ops, shape, variant):
         for mtv in (0, 1):
             want = oracle.pd_tv(x, 0.04, 60, mtv, 1, 12.0, half)
             got = host(PD_TV_cupy(dev(x), 0.04, 60, mtv, 1, 12.0, 0, half))
-            if half and variant == 0:   # shipped build: binary16 duals run the exact arithmetic
-                assert np.array_equal(got, want)
             assert rel(got, want) < (1e-5 if not half else 2e-4), (shape, variant, half, mtv, rel(got, want))
 
 
-@pytest.mark.default_arithmetic
 @pytest.mark.parametrize("shape", TV_SHAPES + [(9, 40, 70)])
 def test_roftv_shipped_arithmetic_is_bit_identical_on_noise(oracle, ops, shape):
     """The shipped ROF_TV (round 3: the reference's sqrt / divide roundings reproduced with FMA correction steps instead
@@ -247,7 +257,7 @@ def test_roftv_shipped_arithmetic_is_bit_identical_on_noise(oracle, ops, shape):
 
 
 @pytest.mark.parametrize("shape", TV_SHAPES)
-@pytest.mark.parametrize("variant", [0, 2, 1])
+@pytest.mark.parametrize("variant", _v(0, 2, 1))
 def test_roftv_vs_oracle(oracle, ops, shape, variant):
     from tomobar_amd.regularisersCuPy import ROF_TV_cupy
     ops.set_variant("roftv", variant)
@@ -261,7 +271,7 @@ def test_roftv_vs_oracle(oracle, ops, shape, variant):
         assert np.array_equal(got, want), (shape, half, np.abs(got - want).max())
 
 
-def test_tv_against_reference_fixtures(golden_dir, ops):
+def test_tv_against_reference_fixtures(golden_dir, ops, float32_duals_only=False):
     """tests/golden/tv_golden.npz: outputs of the reference's own kernel sources (see make_tv_golden.py)."""
     from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
     tv = np.load(os.path.join(golden_dir, "tv_golden.npz"))
@@ -272,6 +282,8 @@ def test_tv_against_reference_fixtures(golden_dir, ops):
         kind, cid = key.split("_")[0], key.split("_")[1]
         m = tv[key]
         x = tv[f"in_{int(m[0])}"]
+        if float32_duals_only and (kind != "pd" or m[1]):
+            continue
         if kind == "pd":
             _, half, mtv, nn, iters, lam, lip = m
             xi = (x - 0.6).astype(np.float32) if nn else x
@@ -282,13 +294,13 @@ def test_tv_against_reference_fixtures(golden_dir, ops):
         for build in ("off", "fma"):
             assert rel(got, tv[f"{kind}_{cid}_{build}"]) < TOL, (key, build)
         n += 1
-    assert n > 60
+    assert n > (20 if float32_duals_only else 60)
 
 
-@pytest.mark.default_arithmetic
-def test_shipped_tv_arithmetic_against_reference_fixtures(golden_dir, ops):
-    """The TV kernels as shipped (relaxed arithmetic) against the outputs of the reference's own kernel sources."""
-    test_tv_against_reference_fixtures(golden_dir, ops)
+def test_relaxed_pdtv_against_reference_fixtures(golden_dir, ops):
+    """The opt-in relaxed PD_TV arithmetic (variant 3, float32 duals) against the outputs of the reference's own kernel sources."""
+    ops.set_variant("pdtv", 3)
+    test_tv_against_reference_fixtures(golden_dir, ops, float32_duals_only=True)
 
 
 def test_tv_errors_and_2d_squeeze():
@@ -355,8 +367,9 @@ def test_pad_crop_mask_permute(oracle, ops):
         assert np.array_equal(host(ops.contiguous(t.permute(*perm))), np.ascontiguousarray(host(t).transpose(perm)))
 
 
+@pytest.mark.parametrize("variants", [(0,), pytest.param((2, 1), marks=DEV)])
 @pytest.mark.parametrize("seed", range(24))
-def test_projector_pair_random_geometries(oracle, ops, seed):
+def test_projector_pair_random_geometries(oracle, ops, seed, variants):
     """seeded random geometries (sizes that are not multiples of any tile, detector wider / narrower than the grid,
     large rotation-axis offsets, arbitrary angle ranges incl. > 360 degrees and descending order, subsets with ragged
     tails): FP and BP of every kernel variant against the oracle, bit for bit"""
@@ -381,24 +394,25 @@ def test_projector_pair_random_geometries(oracle, ops, seed):
             continue
         sino = rng.standard_normal((nz, nsel, nu)).astype(np.float32)
         want_fp, want_bp = P.fp(vol, s), P.bp(sino, s)
-        for v in (0, 2, 1):
+        for v in variants:
             ops.set_variant("fp", v)
             got = host(H.forward(dev(vol), s))
             assert np.array_equal(got, want_fp), ("fp", v, seed, s, (nz, n, nu, na, os_n))
         ops.set_variant("fp", 0)
-        for v in (0, 2, 1):
+        for v in variants:
             ops.set_variant("bp", v)
             got = host(H.backward(dev(sino), s))
             assert np.array_equal(got, want_bp), ("bp", v, seed, s, (nz, n, nu, na, os_n))
         ops.set_variant("bp", 0)
 
 
+@pytest.mark.parametrize("pd_variants", [(0, 3), pytest.param((21,), marks=DEV)])
 @pytest.mark.parametrize("seed", range(3))
-def test_tv_large_odd_shapes(oracle, ops, seed):
+def test_tv_large_odd_shapes(oracle, ops, seed, pd_variants):
     """Large odd-shaped volumes (several z-chunks, hundreds of interior waves running the short form of the z-march
     kernels next to edge waves running the general form, ragged edges in every direction): the shipped three-iteration
-    PD_TV tiling with exact roundings (variant 22 = what binary16 duals ship; 21 = compiler IEEE sequences) and the
-    shipped ROF_TV against the oracle, bit for bit; the shipped float32-dual PD_TV within 1e-5."""
+    PD_TV (variant 0; dev flavour: 21 = compiler IEEE sequences on the same tiling) and the shipped ROF_TV against the
+    oracle, bit for bit; the opt-in relaxed PD_TV (3) within 1e-5 (float32 duals)."""
     from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
     rng = np.random.default_rng(9100 + seed)
     shape = (int(rng.integers(75, 230)), int(rng.integers(150, 420)), int(rng.integers(250, 700)))
@@ -408,25 +422,26 @@ def test_tv_large_odd_shapes(oracle, ops, seed):
     lam = float(rng.choice([0.01, 0.05]))
     want = oracle.pd_tv(x, lam, iters, mtv, nn, 8.0, half)
     xd = dev(x)
-    for v in ([22, 0] if half else [22, 21]):   # variant 0 with binary16 duals IS the exact build
+    for v in pd_variants:
         ops.set_variant("pdtv", v)
         got = host(PD_TV_cupy(xd, lam, iters, mtv, nn, 8.0, 0, half))
-        assert np.array_equal(got, want), ("pd", v, shape, iters, half, mtv, nn, np.abs(got - want).max())
+        if v == 3:
+            assert rel(got, want) < (2e-4 if half else 1e-5), ("pd relaxed", shape, iters, half, mtv, nn, rel(got, want))
+        else:
+            assert np.array_equal(got, want), ("pd", v, shape, iters, half, mtv, nn, np.abs(got - want).max())
     ops.set_variant("pdtv", 0)
-    got = host(PD_TV_cupy(xd, lam, iters, mtv, nn, 8.0, 0, half))
-    assert rel(got, want) < 1e-5, ("pd shipped", shape, iters, half, mtv, nn, rel(got, want))
-    ops.set_variant("roftv", 0)
     want_rof = oracle.rof_tv(x, lam, iters, 0.004, half)
     got = host(ROF_TV_cupy(xd, lam, iters, 0.004, 0, half))
     assert np.array_equal(got, want_rof), ("rof", shape, iters, half, np.abs(got - want_rof).max())
 
 
+@pytest.mark.parametrize("flavour", ["shipped", pytest.param("dev", marks=DEV)])
 @pytest.mark.parametrize("seed", range(16))
-def test_tv_random_shapes(oracle, ops, seed):
+def test_tv_random_shapes(oracle, ops, seed, flavour):
     """seeded random 2D/3D shapes (straddling the 60/62-lane segments, the 4/8-row blocks and the z-chunk boundaries of
-    the z-march kernels), random iteration counts (odd counts end with the single-iteration kernel), every option:
-    the exact-rounding builds of the shipped PD_TV / ROF_TV kernels against the oracle, bit for bit; the shipped
-    (relaxed-arithmetic) builds on the same inputs within 1e-5"""
+    the z-march kernels), random iteration counts (odd counts end with the single-iteration kernel), every option.
+    shipped: PD_TV / ROF_TV as shipped against the oracle, bit for bit, and the opt-in relaxed PD_TV within tolerance;
+    dev: the builds with the compiler's IEEE sequences (pdtv 2, 21; roftv 2), bit for bit."""
     from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
     rng = np.random.default_rng(2000 + seed)
     if seed % 4 == 0:
@@ -437,22 +452,16 @@ def test_tv_random_shapes(oracle, ops, seed):
     iters = int(rng.integers(1, 9))
     half, mtv, nn = bool(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
     lam = float(rng.choice([0.01, 0.05, 0.3]))
-    ops.set_variant("pdtv", 2)
-    ops.set_variant("roftv", 2)
     want_pd = oracle.pd_tv(x, lam, iters, mtv, nn, 8.0, half)
-    got = host(PD_TV_cupy(dev(x), lam, iters, mtv, nn, 8.0, 0, half))
-    assert np.array_equal(got, want_pd), ("pd", shape, iters, half, mtv, nn, np.abs(got - want_pd).max())
-    for v in (21, 22):  # exact arithmetic on the SHIPPED three-iteration tiling: compiler IEEE / FMA-corrected roundings
+    want_rof = oracle.rof_tv(x, lam, iters, 0.004, half)
+    for v in ((0,) if flavour == "shipped" else (2, 21)):
         ops.set_variant("pdtv", v)
         got = host(PD_TV_cupy(dev(x), lam, iters, mtv, nn, 8.0, 0, half))
-        assert np.array_equal(got, want_pd), ("pd K=3", v, shape, iters, half, mtv, nn, np.abs(got - want_pd).max())
-    want_rof = oracle.rof_tv(x, lam, iters, 0.004, half)
+        assert np.array_equal(got, want_pd), ("pd", v, shape, iters, half, mtv, nn, np.abs(got - want_pd).max())
+    ops.set_variant("roftv", 0 if flavour == "shipped" else 2)
     got = host(ROF_TV_cupy(dev(x), lam, iters, 0.004, 0, half))
     assert np.array_equal(got, want_rof), ("rof", shape, iters, half, np.abs(got - want_rof).max())
-    ops.set_variant("pdtv", 0)
-    ops.set_variant("roftv", 0)
-    tol = 1e-5   # binary16 duals keep the exact arithmetic in the shipped build (bit-identical)
-    got = host(PD_TV_cupy(dev(x), lam, iters, mtv, nn, 8.0, 0, half))
-    assert rel(got, want_pd) < tol, ("pd shipped", shape, iters, half, mtv, nn, rel(got, want_pd))
-    got = host(ROF_TV_cupy(dev(x), lam, iters, 0.004, 0, half))
-    assert np.array_equal(got, want_rof), ("rof shipped", shape, iters, half, rel(got, want_rof))
+    if flavour == "shipped":
+        ops.set_variant("pdtv", 3)
+        got = host(PD_TV_cupy(dev(x), lam, iters, mtv, nn, 8.0, 0, half))
+        assert rel(got, want_pd) < (2e-4 if half else 1e-5), ("pd relaxed", shape, iters, half, mtv, nn, rel(got, want_pd))

@@ -72,10 +72,13 @@ CASES = {
 }
 
 
-@pytest.mark.default_arithmetic
-@pytest.mark.parametrize("name", sorted(k for k, c in CASES.items() if c[4] is not None))
-def test_shipped_tv_arithmetic_against_reference_python_loops(outer, geom, name):
-    """The same reconstructions with the TV kernels as shipped (relaxed arithmetic), against the reference's own loops."""
+@pytest.mark.parametrize("name", sorted(k for k, c in CASES.items() if c[4] is not None and c[4]["method"] == "PD_TV"
+                                        and not c[4].get("half_precision")))
+def test_relaxed_pdtv_against_reference_python_loops(outer, geom, name):
+    """The same reconstructions with the opt-in relaxed PD_TV arithmetic (variant 3, float32 duals), against the
+    reference's own loops."""
+    from tomobar_amd import ops
+    ops.set_variant("pdtv", 3)
     test_against_reference_python_loops(outer, geom, name)
 
 
@@ -199,11 +202,12 @@ def test_simple_iterative_methods_vs_oracle(oracle, geom):
     assert rel(got, x.reshape(nz, n, n)) < 1e-4  # inner products accumulate in a different order
 
 
-@pytest.mark.default_arithmetic
-def test_medium_size_fista_os_pdtv_shipped_arithmetic(oracle):
-    """The shipped (relaxed-arithmetic) PD_TV inside a FISTA-OS run of several outer iterations: <= 1e-5 from the oracle
+def test_medium_size_fista_os_pdtv_relaxed_arithmetic(oracle):
+    """The opt-in relaxed PD_TV (variant 3) inside a FISTA-OS run of several outer iterations: <= 1e-5 from the oracle
     (north-star tolerance), i.e. the per-call 1e-7 differences do not grow through the outer loop."""
+    from tomobar_amd import ops
     from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    ops.set_variant("pdtv", 3)
     nz, det, na, os_n = 12, 160, 72, 6
     angles = np.linspace(0, np.pi, na, endpoint=False)
     sino = oracle.shepp_logan_sino(det, nz, det, angles) / det
@@ -217,7 +221,7 @@ def test_medium_size_fista_os_pdtv_shipped_arithmetic(oracle):
                    {"iterations": 5, "lipschitz_const": Lc, "nonnegativity": True, "recon_mask_radius": None},
                    {"method": "PD_TV", "regul_param": 0.002, "iterations": 30})
     r = rel(host(rec), want)
-    print("FISTA-OS(6) x 5 + PD_TV(30), shipped arithmetic: rel-L2 vs oracle =", r)
+    print("FISTA-OS(6) x 5 + PD_TV(30), relaxed arithmetic: rel-L2 vs oracle =", r)
     assert r < TOL, r
 
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtomo_mi355x.so")
 
 OK, E_INVALID, E_RUNTIME, E_NOMEM, E_NODEVICE = 0, 1, 2, 3, 4
-ABI_VERSION = 2  # TOMO_ABI_VERSION of include/tomo_mi355x.h (tests/test_host_logic.py keeps the two in step)
+ABI_VERSION = 3  # TOMO_ABI_VERSION of include/tomo_mi355x.h (tests/test_host_logic.py keeps the two in step)
 FLAG_LERP8 = 1
 FID = {"LS": 0, "PWLS": 1, "KL": 2, "RATIO": 3}
 
@@ -29,6 +29,7 @@ _vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 # name -> (restype, argtypes); kept in one table so tests can check it against the header
 SIGNATURES = {
     "tomo_abi_version": (_i, []),
+    "tomo_build_flavour": (C.c_char_p, []),
     "tomo_last_error": (C.c_char_p, []),
     "tomo_device_count": (_i, [C.POINTER(_i)]),
     "tomo_ctx_create": (_i, [_i, _i, _i, _i, _i, C.POINTER(_d), C.POINTER(_d), _i, _i, C.c_uint, C.POINTER(_vp)]),
@@ -101,42 +102,80 @@ SIGNATURES = {
     "tomo_profile_read": (_i, [C.c_char_p, C.POINTER(C.c_longlong), C.POINTER(_d)]),
 }
 
-_lib = None
+LIB_PATHS = {"shipped": LIB_PATH, "dev": os.path.join(_HERE, "libtomo_mi355x_dev.so")}
+_handles = {}
+_flavour = "dev" if os.environ.get("TOMO_MI355X_FLAVOUR", "shipped") == "dev" else "shipped"
 
 
 class TomoRuntimeError(RuntimeError):
     pass
 
 
+def _load(flavour: str):
+    path = LIB_PATHS[flavour]
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: the HIP extension is required (no CPU fallback). "
+            f"Build it with `make -C tomobar_amd/csrc{' dev' if flavour == 'dev' else ''}` or `__graft_entry__.build()`.")
+    handle = C.CDLL(path)
+    missing = [name for name in SIGNATURES if not hasattr(handle, name)]
+    if missing:
+        raise ImportError(f"{path} is stale: it does not export {missing[:4]}{'...' if len(missing) > 4 else ''}; "
+                          "rebuild it (make -C tomobar_amd/csrc all)")
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+    if handle.tomo_abi_version() != ABI_VERSION:
+        raise ImportError(f"{os.path.basename(path)} has ABI version {handle.tomo_abi_version()}, this package binds "
+                          f"version {ABI_VERSION}: rebuild it (make -C tomobar_amd/csrc all)")
+    if handle.tomo_build_flavour().decode() != flavour:
+        raise ImportError(f"{path} reports flavour {handle.tomo_build_flavour().decode()!r}, expected {flavour!r}")
+    return handle
+
+
 def lib():
-    """Load the shared library (once).  Raises ImportError with build instructions if it is absent."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(
-                f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
-                "Build it with `make -C tomobar_amd/csrc` or `__graft_entry__.build()`.")
-        handle = C.CDLL(LIB_PATH)
-        missing = [name for name in SIGNATURES if not hasattr(handle, name)]
-        if missing:
-            raise ImportError(f"{LIB_PATH} is stale: it does not export {missing[:4]}{'...' if len(missing) > 4 else ''}; "
-                              "rebuild it (make -C tomobar_amd/csrc)")
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(handle, name)
-            fn.restype = res
-            fn.argtypes = args
-        if handle.tomo_abi_version() != ABI_VERSION:
-            raise ImportError(f"libtomo_mi355x.so has ABI version {handle.tomo_abi_version()}, this package binds "
-                              f"version {ABI_VERSION}: rebuild it (make -C tomobar_amd/csrc)")
-        _lib = handle
-    return _lib
+    """The loaded shared library of the current flavour (loaded once).  Raises ImportError with build instructions if it
+    is absent.  The product always runs "shipped" (libtomo_mi355x.so); `use_flavour("dev")` -- or TOMO_MI355X_FLAVOUR=dev in
+    the environment -- points the package at libtomo_mi355x_dev.so, the build that also carries the independent kernel
+    implementations and measurement switches tests/ and tools/ compare against."""
+    h = _handles.get(_flavour)
+    if h is None:
+        h = _handles[_flavour] = _load(_flavour)
+    return h
 
 
-def check(rc: int):
-    """Map a C-ABI status to the exception type the reference raises for the same condition."""
+def flavour() -> str:
+    return _flavour
+
+
+class use_flavour:
+    """Context manager / plain call: make `lib()` return the given flavour.  The two libraries are independent (their own
+    contexts, scratch arenas and variant switches): objects created under one flavour keep calling it (HipTools3D stores
+    its handle), so flavours can be mixed in one process as long as native handles are not passed across."""
+
+    def __init__(self, name: str):
+        global _flavour
+        if name not in LIB_PATHS:
+            raise ValueError(f"unknown library flavour {name!r}")
+        self.prev = _flavour
+        _flavour = name
+
+    def __enter__(self):
+        return lib()
+
+    def __exit__(self, *exc):
+        global _flavour
+        _flavour = self.prev
+        return False
+
+
+def check(rc: int, handle=None):
+    """Map a C-ABI status to the exception type the reference raises for the same condition.  `handle`: the library the
+    call went to (default: the current flavour)."""
     if rc == OK:
         return
-    msg = lib().tomo_last_error().decode("utf-8", "replace")
+    msg = (handle or lib()).tomo_last_error().decode("utf-8", "replace")
     if rc == E_INVALID:
         raise ValueError(msg)
     if rc == E_NOMEM:

@@ -26,7 +26,11 @@ struct FpTiledArgs {
     int wpitch;              // LDS pitch (float4 units) per staged row, <= 256 * passes <= 1024
     int nut, ngroups, nzb;   // detector tiles, angle groups, slice quads
     int bt;                  // whole-row form: detector pixels per tile = threads launched (a multiple of 64, <= 1024)
-    int probe;               // measurement only (tools/fp_stage_probe.py): 16 = skip the staging (global loads + LDS writes)
+#if TOMO_DEV
+    int probe;               // measurement only (tools/fp_stage_probe.py): 16 = skip the staging (global loads + LDS writes), 32 = the LDS writes only
+#else
+    static constexpr int probe = 0;  // the shipped flavour carries no measurement switches
+#endif
 };
 
 // BT = workgroup size = detector pixels per workgroup.  256: several workgroups per CU.  1024: the workgroup spans the

@@ -430,6 +430,17 @@ static int pd_zmarch_xk_launch(PdArgs a, hipStream_t st, long want_per_simd = 32
     a.inv1lt = 1.0f / (1.0f + a.lt);
     const long blocks = 8L * tiles_per_xcd * chunks;
     if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one PD_TV launch");
-    pd_zmarch_xk_kernel<T, NONNEG, ANISO, FAST, K, RY, WX, WY, LAG, LREG><<<(unsigned)blocks, 64 * WX * WY, 0, st>>>(a, gx, gy, tiles_per_xcd);
+    size_t dyn = 0;
+#if TOMO_DEV
+    // measurement only (tools/pd_halo_probe.py, bit 8): reserve 72 KiB of dynamic LDS on top of the kernel's own 80 KiB, so
+    // that ONE workgroup fits a CU (one wave per SIMD instead of two) -- what a tiling that spends the second workgroup's
+    // LDS on a prefetch buffer would have to live with
+    if (a.probe & 8) {
+        dyn = 72 * 1024;
+        (void)hipFuncSetAttribute((const void *)pd_zmarch_xk_kernel<T, NONNEG, ANISO, FAST, K, RY, WX, WY, LAG, LREG>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    }
+#endif
+    pd_zmarch_xk_kernel<T, NONNEG, ANISO, FAST, K, RY, WX, WY, LAG, LREG><<<(unsigned)blocks, 64 * WX * WY, dyn, st>>>(a, gx, gy, tiles_per_xcd);
     return TOMO_OK;
 }

@@ -307,7 +307,9 @@ int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
         if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one BP launch");
         if (lerp8) bp_brick_kernel<EPI, true><<<(unsigned)blocks, 256, 0, st>>>(a);
         else bp_brick_kernel<EPI, false><<<(unsigned)blocks, 256, 0, st>>>(a);
-    } else {
+    }
+#if TOMO_DEV
+    else {  // variant 2 (dev flavour): the round-1 tiling with lanes along x, kept for A/B measurement
         if (a.path) *a.path = "tiled(64x8x16)";
         a.ntx = ceil_div(a.n, BP_TX);
         a.nty = ceil_div(a.n, BP_TY);
@@ -317,6 +319,7 @@ int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
         if (lerp8) bp_tiled_kernel<EPI, true><<<(unsigned)blocks, 256, 0, st>>>(a);
         else bp_tiled_kernel<EPI, false><<<(unsigned)blocks, 256, 0, st>>>(a);
     }
+#endif
     TOMO_LAUNCH_CHECK();
     return TOMO_OK;
 }
@@ -553,7 +556,9 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
             t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
             t.ring = ring; t.ring_scale = ring_scale;
             t.wpitch = wp;
+#if TOMO_DEV
             t.probe = g_probe;
+#endif
             t.nut = nut_w;
             t.bt = bt;
             t.ngroups = ceil_div(nc, FP_A);
@@ -631,7 +636,9 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
                 t.ring = ring; t.ring_scale = ring_scale;
                 t.wpitch = s.wbound[c];
-                t.probe = g_probe;
+    #if TOMO_DEV
+            t.probe = g_probe;
+#endif
                 const int passes = ceil_div(t.wpitch, 256);           // 1..5 in the pipelined kernel
                 // (items per thread, double buffer) per pass count -- keep in step with FP_TILED_LAUNCH below
                 const int fp_m = passes <= 2 ? 8 : (passes == 5 ? 10 : 12);

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <mutex>
 #include <new>
@@ -22,9 +23,12 @@ int tomo_fail(int code, const char *fmt, ...)
 
 // test / A-B switches (tomo_set_variant), per host thread: one thread's choice never changes what another launches
 thread_local int g_variant_bp = 0, g_variant_fp = 0, g_variant_pdtv = 0, g_variant_roftv = 0;
-thread_local int g_probe = 0;  // measurement-only switches of tools/ (tomo_set_variant("probe", bits)); 0 in every product path
+#if TOMO_DEV
+thread_local int g_probe = 0;  // measurement-only switches of tools/ (tomo_set_variant("probe", bits)); dev flavour only
+#endif
 
 extern "C" int tomo_abi_version(void) { return TOMO_ABI_VERSION; }
+extern "C" const char *tomo_build_flavour(void) { return TOMO_DEV ? "dev" : "shipped"; }
 extern "C" const char *tomo_last_error(void) { return g_err; }
 
 extern "C" int tomo_device_count(int *count)
@@ -45,12 +49,27 @@ extern "C" int tomo_set_variant(const char *kernel, int variant)
 {
     TOMO_REQUIRE(kernel != nullptr, "kernel name is NULL");
     std::string k(kernel);
-    if (k == "bp") g_variant_bp = variant;
-    else if (k == "fp") g_variant_fp = variant;
-    else if (k == "pdtv") g_variant_pdtv = variant;
-    else if (k == "roftv") g_variant_roftv = variant;
-    else if (k == "probe") g_probe = variant;
-    else return tomo_fail(TOMO_E_INVALID, "unknown kernel '%s'", kernel);
+    // what each flavour was compiled with (tomo_common.h): selecting a variant whose kernels are not in this library is an
+    // error, never a silent fall-through to another kernel
+    auto allowed = [&](std::initializer_list<int> shipped, std::initializer_list<int> dev) {
+        for (int v : shipped) if (v == variant) return true;
+        if (TOMO_DEV) for (int v : dev) if (v == variant) return true;
+        return false;
+    };
+    int *slot = nullptr;
+    bool ok = false;
+    if (k == "bp") { slot = &g_variant_bp; ok = allowed({0}, {1, 2}); }
+    else if (k == "fp") { slot = &g_variant_fp; ok = allowed({0}, {1, 2}); }
+    else if (k == "pdtv") { slot = &g_variant_pdtv; ok = allowed({0, 3}, {1, 2, 21}); }
+    else if (k == "roftv") { slot = &g_variant_roftv; ok = allowed({0}, {1, 2, 3, 4}); }
+#if TOMO_DEV
+    else if (k == "probe") { g_probe = variant; return TOMO_OK; }
+#endif
+    else return tomo_fail(TOMO_E_INVALID, "unknown kernel '%s'%s", kernel,
+                          (!TOMO_DEV && k == "probe") ? " (measurement switches exist in libtomo_mi355x_dev.so only)" : "");
+    if (!ok) return tomo_fail(TOMO_E_INVALID, "variant %d of '%s' is not part of this library (%s flavour)%s", variant, kernel,
+                              tomo_build_flavour(), TOMO_DEV ? "" : ": the A/B variants live in libtomo_mi355x_dev.so");
+    *slot = variant;
     return TOMO_OK;
 }
 

@@ -4,17 +4,19 @@
 //   tomobar/cuda_kernels/primal_dual_for_total_variation.cu:125-261 (3D), :360-452 (2D)
 //   tomobar/cuda_kernels/rudin_osher_fatemi_total_variation.cu:66-137 (2D), :156-238 (3D)
 // How it is computed here is MI355X-first:
-//   * PD_TV default (float32 duals): pd_zmarch_xk.inl, THREE iterations per pass through HBM.  A lane owns 8 consecutive
-//     rows of one x column and marches along z; +-y neighbours are other registers of the same lane, +-x neighbours come
-//     from DPP wave shifts (3 halo lanes either side), the z-1 duals are carried, stage s (iteration n+s -> n+s+1) runs
-//     s planes behind stage 0 in the same wave and the hand-over state lives in private LDS slots.  Two iterations per
-//     pass (binary16 duals, remainders): pd_zmarch_x2.inl; one iteration (tails, 2D): pd_zmarch2.inl.
-//     Measured history and PMC evidence: DESIGN.md sections 4 and 6.
-//   * variant 1 ("pervoxel"): one thread per voxel, neighbours' duals recomputed from global memory -- the independent
-//     implementation kept for A/B checks; variants 2 / 21: the exact-rounding builds of the shipped kernels.
+//   * PD_TV: pd_zmarch_xk.inl, THREE iterations per pass through HBM.  A lane owns 8 consecutive rows of one x column and
+//     marches along z; +-y neighbours are other registers of the same lane, +-x neighbours come from DPP wave shifts (3
+//     halo lanes either side), the z-1 duals are carried, stage s (iteration n+s -> n+s+1) runs s planes behind stage 0
+//     in the same wave and the hand-over state lives in private LDS slots.  Two iterations per pass (launch remainders):
+//     pd_zmarch_x2.inl; one iteration (tails, 2D, thin volumes): pd_zmarch2.inl; 2D images: pd_rows2d.inl (three
+//     iterations per pass, rows in registers).  Measured history and PMC evidence: DESIGN.md sections 4 and 6.
 //   * ROF_TV: rof_zmarch.inl, divergence and update fused on the same z-march skeleton: the D fields never reach
-//     HBM (12 B/voxel/iteration) and are evaluated once per voxel.  Variant 1: per-voxel form.
-// All arithmetic is float32 with the rounding sequence of oracle/tomo_oracle.c (explicit fmaf, -ffp-contract=off).
+//     HBM (12 B/voxel/iteration) and are evaluated once per voxel.
+//   * -DTOMO_DEV_VARIANTS (libtomo_mi355x_dev.so, tests / tools only): the per-voxel kernels (variant 1: one thread per
+//     voxel, neighbours' duals recomputed from global memory -- the independent implementation) and the builds with the
+//     compiler's IEEE sqrt / divide (2, 21) or relaxed ROF arithmetic.
+// All arithmetic is float32 with the rounding sequence of oracle/tomo_oracle.c (explicit fmaf, -ffp-contract=off); the
+// shipped default reproduces the reference's roundings for float32 AND binary16 duals (round 4).
 #include "tomo_common.h"
 #include <algorithm>
 #include <utility>
@@ -200,9 +202,14 @@ struct PdArgs {
     float inv1lt;     // 1 / (1 + lt), relaxed-arithmetic kernels only
     int p_in_zero = 0;   // pd_zmarch_xk: the input duals are all zero (first launch of a prox): do not read them
     int p_out_skip = 0;  // pd_zmarch_xk: do not store the output duals (last launch of a prox)
+#if TOMO_DEV
     int probe = 0;       // measurement only (tools/pd_halo_probe.py): 1 = alias the y halo rows, 2 = the x halo lanes onto the workgroup's own tile, 4 = every plane access goes to plane 0 (cache-resident: what the kernel costs without HBM)
+#else
+    static constexpr int probe = 0;  // the shipped flavour carries no measurement switches
+#endif
 };
 
+#if TOMO_DEV
 // ------------------------------------------------------------------------------------------ PD variant 1
 // forward difference with the far-edge mirror (primal_dual...cu:216-220) and zero "previous" at index 0 (:147-160)
 __device__ __forceinline__ float fwd_diff(const float *U, size_t idx, int i, int dim, size_t stride, bool edge_last)
@@ -249,6 +256,8 @@ __global__ __launch_bounds__(256) void pd_pervoxel_kernel(PdArgs a)
 #pragma unroll
     for (int c = 0; c < ND; ++c) DualIO<T>::st((T *)a.p_out[c], idx, p[c]);
 }
+
+#endif  // TOMO_DEV
 
 // FAST = 0: arithmetic and rounding of the reference through the compiler's IEEE sqrt / divide (bit-identical to the oracle).
 // FAST = 1: 1/(1+lt) hoisted to the host, v_rsq_f32 / v_rcp_f32 instead of IEEE sqrt + divide (<= 1e-6 relative).
@@ -410,55 +419,53 @@ __device__ __forceinline__ void pd_primal_block(float (&out)[NB], const float (&
 #include "pd_zmarch2.inl"
 #include "pd_zmarch_x2.inl"
 #include "pd_zmarch_xk.inl"
+#include "pd_rows2d.inl"
 
 // Several iterations in one pass through HBM (3D).  `k` = iterations of this launch (2 or 3).
-//   variant 0 (shipped): k = 3 -> pd_zmarch_xk<K=3, 8 rows, 2x2 waves, LDS lag>; float32 duals: relaxed arithmetic
-//                        (k = 2 remainders -> pd_zmarch_x2<2x4 waves>); binary16 duals: the reference's roundings through FMA
-//                        correction steps (FAST = 2; one flipped binary16 rounding is 5e-4 of a dual value: relaxed
-//                        arithmetic cannot hold the 1e-5 parity bar) -- round 3: 3.85 instead of 3.97 ms per iteration
-//   variant 2: the reference's exact rounding sequence through the compiler's IEEE sqrt / divide, k = 2 (pd_zmarch_x2,
-//              2x2 waves; bit-identical to the oracle)
-//   variant 3: relaxed arithmetic for both dual types, k = 2
-//   variant 21: pd_zmarch_xk K = 3 with the compiler's IEEE arithmetic on the shipped tiling (bit-identical to the oracle)
-//   variant 22: pd_zmarch_xk K = 3 with the FMA-corrected roundings for both dual types (bit-identical to the oracle;
-//               float32 duals 3.68 ms per iteration against 3.30 relaxed and 4.43 for variant 21)
-static int pd_iters_per_launch(int variant, int half)
+//   variant 0 (shipped default): the reference's roundings through FMA correction steps (FAST = 2) for float32 and
+//              binary16 duals: k = 3 -> pd_zmarch_xk<K=3, 8 rows, 2x2 waves, LDS lag>, k = 2 -> pd_zmarch_x2<2x2 waves>.
+//              Bit-identical to the oracle.  (Rounds 2-3 shipped relaxed arithmetic for float32 duals; measured on the
+//              final round-3 kernels the exact build costs 1-2 %: 3.94 vs 4.01 ms per 1024^3 iteration in a
+//              10-iteration call, profiles/r4a_kernel_bench_1024.txt -- parity is worth more than that.)
+//   variant 3 (shipped, opt-in): relaxed arithmetic for both dual types on the same tilings -- v_rsq_f32 instead of
+//              1 / sqrtf, a host-computed 1 / (1 + lt) instead of the divide; <= 1e-5 from the default on float32 duals.
+//   variant 2 (dev): the compiler's IEEE sqrt / divide sequences, two iterations per launch (pd_zmarch_x2, 2x2 waves);
+//   variant 21 (dev): the same on the K = 3 tiling.  Both bit-identical to the oracle: the independent exactness check.
+static int pd_iters_per_launch(int variant)
 {
-    (void)half;
-    if (variant == 21 || variant == 22 || variant == 31 || variant == 0) return 3;
-    return 2;
+    if (variant == 1) return 1;
+    return variant == 2 ? 2 : 3;
 }
 
-// three iterations per launch.  float32 duals: 8 rows per lane, 10 of the 90 hand-over slots in registers (80 KB of LDS
-// per workgroup = two workgroups per CU), relaxed (shipped) or exact (variant 21) arithmetic on the same tiling;
-// binary16 duals (variant 21 only): 4 rows per lane, exact arithmetic
+// three iterations per launch: 8 rows per lane, 10 of the 90 hand-over slots in registers (80 KB of LDS per workgroup = two
+// workgroups per CU)
 template <typename T, bool NN, bool AN>
 int pd_xk3_launch(const PdArgs &a, int variant, hipStream_t st)
 {
-    if (variant == 22) return pd_zmarch_xk_launch<T, NN, AN, 2, 3, 8, 2, 2, true, 10>(a, st);  // FMA-corrected exact roundings
-    if (variant == 31) return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 2, 2, true, 10>(a, st);  // measurement: relaxed for both dual types
-    if constexpr (sizeof(T) == 4) {
-        if (variant == 21) return pd_zmarch_xk_launch<T, NN, AN, 0, 3, 8, 2, 2, true, 10>(a, st);
-        return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 2, 2, true, 10>(a, st);
-    } else {
-        // binary16 duals: exact roundings always (one flipped binary16 rounding is 5e-4 of a dual value); shipped = the
-        // FMA-corrected form on the 8-row tiling (3.85 ms per 1024^3 iteration; compiler IEEE on 4 rows, variant 21: 5.9)
-        if (variant == 21) return pd_zmarch_xk_launch<T, NN, AN, 0, 3, 4, 2, 2, true>(a, st);
-        return pd_zmarch_xk_launch<T, NN, AN, 2, 3, 8, 2, 2, true, 10>(a, st);
+    if (variant == 3) return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 2, 2, true, 10>(a, st);
+#if TOMO_DEV
+    if (variant == 21) {
+        if constexpr (sizeof(T) == 4) return pd_zmarch_xk_launch<T, NN, AN, 0, 3, 8, 2, 2, true, 10>(a, st);
+        else return pd_zmarch_xk_launch<T, NN, AN, 0, 3, 4, 2, 2, true>(a, st);  // 4 rows per lane: the IEEE expansions need the registers
     }
+#endif
+    return pd_zmarch_xk_launch<T, NN, AN, 2, 3, 8, 2, 2, true, 10>(a, st);
+}
+
+template <typename T, bool NN, bool AN>
+int pd_x2_launch(const PdArgs &a, int variant, hipStream_t st)
+{
+    if (variant == 3) return pd_zmarch_x2_launch<T, NN, AN, 1, 4, 2, 4>(a, st);
+#if TOMO_DEV
+    if (variant == 2 || variant == 21) return pd_zmarch_x2_launch<T, NN, AN, 0, 4, 2, 2>(a, st);
+#endif
+    return pd_zmarch_x2_launch<T, NN, AN, 2, 4, 2, 2>(a, st);
 }
 
 template <typename T>
 int pd_multi_launch(const PdArgs &a, int k, int methodTV, int nonneg, int variant, hipStream_t st)
 {
-    constexpr bool F32 = sizeof(T) == 4;
-#define PD_XK(NN, AN)                                                                                   \
-    (k == 3 ? pd_xk3_launch<T, NN, AN>(a, variant, st)                                                   \
-     : variant == 22 ? pd_zmarch_x2_launch<T, NN, AN, 2, 4, 2, 2>(a, st)                                 \
-     : variant == 3  ? pd_zmarch_x2_launch<T, NN, AN, true, 4, 2, 4>(a, st)                              \
-     : (variant == 2 || variant == 21) ? pd_zmarch_x2_launch<T, NN, AN, false, 4, 2, 2>(a, st)           \
-     : F32 ? pd_zmarch_x2_launch<T, NN, AN, true, 4, 2, 4>(a, st)                                        \
-           : pd_zmarch_x2_launch<T, NN, AN, 2, 4, 2, 2>(a, st))
+#define PD_XK(NN, AN) (k == 3 ? pd_xk3_launch<T, NN, AN>(a, variant, st) : pd_x2_launch<T, NN, AN>(a, variant, st))
     int rc;
     if (!nonneg && !methodTV) rc = PD_XK(false, false);
     else if (nonneg && !methodTV) rc = PD_XK(true, false);
@@ -470,26 +477,58 @@ int pd_multi_launch(const PdArgs &a, int k, int methodTV, int nonneg, int varian
     return TOMO_OK;
 }
 
+// 2D images: k (1, 2 or 3) iterations per launch, rows in registers (pd_rows2d.inl); the arithmetic follows the variant
+template <typename T, bool NN, bool AN, int FAST>
+int pd_rows2d_k(const PdArgs &a, int k, hipStream_t st)
+{
+    if (k == 3) return pd_rows2d_launch<T, NN, AN, FAST, 3, 8>(a, st);
+    if (k == 2) return pd_rows2d_launch<T, NN, AN, FAST, 2, 8>(a, st);
+    return pd_rows2d_launch<T, NN, AN, FAST, 1, 8>(a, st);
+}
+
+template <typename T>
+int pd_2d_launch(const PdArgs &a, int k, int methodTV, int nonneg, int variant, hipStream_t st)
+{
+#if TOMO_DEV
+#define PD_2D_F(NN, AN) (variant == 3 ? pd_rows2d_k<T, NN, AN, 1>(a, k, st) : (variant == 2 || variant == 21) ? pd_rows2d_k<T, NN, AN, 0>(a, k, st) : pd_rows2d_k<T, NN, AN, 2>(a, k, st))
+#else
+#define PD_2D_F(NN, AN) (variant == 3 ? pd_rows2d_k<T, NN, AN, 1>(a, k, st) : pd_rows2d_k<T, NN, AN, 2>(a, k, st))
+#endif
+    int rc;
+    if (!nonneg && !methodTV) rc = PD_2D_F(false, false);
+    else if (nonneg && !methodTV) rc = PD_2D_F(true, false);
+    else if (!nonneg && methodTV) rc = PD_2D_F(false, true);
+    else rc = PD_2D_F(true, true);
+#undef PD_2D_F
+    if (rc != TOMO_OK) return rc;
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
 template <typename T, int ND, bool NONNEG, bool ANISO>
 int pd_launch(const PdArgs &a0, int variant, hipStream_t st)
 {
     PdArgs a = a0;
     const int nout = a.out_end - a.out_begin;
     if (nout <= 0 || a.dx <= 0 || a.dy <= 0) return TOMO_OK;
+    // measured on MI355X, 1024^3 f32 duals (profiles/r1_pdtv_pmc.txt): 4x2 waves x 8 rows, lockstep = 8.6 ms;
+    // 4x4 waves x 4 rows = 9.2 ms; 4x1 x 8 rows = 8.7 ms; unsynchronised waves (1x4, 4 rows) = 12.3-14 ms.
+    // The arithmetic of an iteration never depends on how a run is cut into launches (slabs cut it differently): the
+    // single-iteration kernel follows the variant's arithmetic like the fused ones.
+    int rc;
+#if TOMO_DEV
     if (variant == 1) {
         dim3 grid(ceil_div(a.dx, 256), a.dy, nout);
         pd_pervoxel_kernel<T, ND, NONNEG, ANISO><<<grid, 256, 0, st>>>(a);
-    } else {
-        // measured on MI355X, 1024^3 f32 duals (profiles/r1_pdtv_pmc.txt): 4x2 waves x 8 rows, lockstep = 8.6 ms;
-        // 4x4 waves x 4 rows = 9.2 ms; 4x1 x 8 rows = 8.7 ms; unsynchronised waves (1x4, 4 rows) = 12.3-14 ms
-        // the shipped build (variant 0) runs float32 duals with relaxed arithmetic, like the multi-iteration kernels:
-        // the arithmetic of an iteration must not depend on how a run is cut into launches (slabs cut it differently)
-        const bool relaxed = (variant == 3) || (variant == 0 && sizeof(T) == 4);
-        int rc = (variant == 22 || (variant == 0 && sizeof(T) == 2)) ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 2, 8, true, 4, 2>(a, st)
-                 : relaxed ? pd_zmarch2_launch<T, ND, NONNEG, ANISO, 1, 8, true, 4, 2>(a, st)
-                           : pd_zmarch2_launch<T, ND, NONNEG, ANISO, 0, 8, true, 4, 2>(a, st);
-        if (rc != TOMO_OK) return rc;
+        TOMO_LAUNCH_CHECK();
+        return TOMO_OK;
     }
+    if (variant == 2 || variant == 21) rc = pd_zmarch2_launch<T, ND, NONNEG, ANISO, 0, 8, true, 4, 2>(a, st);
+    else
+#endif
+    if (variant == 3) rc = pd_zmarch2_launch<T, ND, NONNEG, ANISO, 1, 8, true, 4, 2>(a, st);
+    else rc = pd_zmarch2_launch<T, ND, NONNEG, ANISO, 2, 8, true, 4, 2>(a, st);
+    if (rc != TOMO_OK) return rc;
     TOMO_LAUNCH_CHECK();
     return TOMO_OK;
 }
@@ -505,10 +544,13 @@ int pd_dispatch(const PdArgs &a, int methodTV, int nonneg, int variant, hipStrea
 
 int pd_iter(const PdArgs &a, int nd, int methodTV, int nonneg, int half, hipStream_t st)
 {
-    // 1: per-voxel kernel; 0 / 3: z-march with the shipped / relaxed arithmetic; everything else: exact z-march
-    const int v = (g_variant_pdtv == 1 || g_variant_pdtv == 0 || g_variant_pdtv == 3 || g_variant_pdtv == 11 || g_variant_pdtv == 22) ? (g_variant_pdtv == 11 ? 3 : g_variant_pdtv) : 2;
+    const int v = g_variant_pdtv;
     if (nd == 3) return half ? pd_dispatch<__half, 3>(a, methodTV, nonneg, v, st) : pd_dispatch<float, 3>(a, methodTV, nonneg, v, st);
-    return half ? pd_dispatch<__half, 2>(a, methodTV, nonneg, v, st) : pd_dispatch<float, 2>(a, methodTV, nonneg, v, st);
+#if TOMO_DEV
+    return half ? pd_dispatch<__half, 2>(a, methodTV, nonneg, v, st) : pd_dispatch<float, 2>(a, methodTV, nonneg, v, st);  // per-voxel 2D kernel (variant 1)
+#else
+    return tomo_fail(TOMO_E_INVALID, "internal: 2D PD_TV runs pd_rows2d in this library");
+#endif
 }
 
 // ------------------------------------------------------------------------------------------ ROF
@@ -538,6 +580,7 @@ __device__ __forceinline__ float rof_norm(float nom, float d1, float d2, float d
     return nom / den;
 }
 
+#if TOMO_DEV
 // D component `comp` (0: pairs with y/j, 1: with x/i, 2: with z/k) at voxel (i,j,k)
 template <int ND, bool HALF>
 __device__ __forceinline__ float rof_D(const RofArgs &a, int i, int j, int k, int comp)
@@ -589,22 +632,29 @@ __global__ __launch_bounds__(256) void rof_pervoxel_kernel(RofArgs a)
     a.u_out[idx] = fmaf(a.tau, t, u);
 }
 
+#endif  // TOMO_DEV
+
 #include "rof_zmarch.inl"
 
 // variant 0 (shipped, float32 and binary16 D fields): the reference's rounding sequence reproduced with FMA correction
-//            steps (rof_eval FAST = 3): bit-identical to the oracle, 4.2 ms per 1024^3 iteration;
-//         2: the same roundings through the compiler's IEEE sqrt / divide expansions (independent check, 4.8 ms);
-//         3: relaxed arithmetic (float32 sum + v_rsq_f32, 2.95 ms) -- measurement only: the D normalisation has a gain of
-//            ~1e4 on noise-dominated data, where one-ulp differences grow to 2.5e-5 .. 4.5e-5 after 60 iterations
-//            (profiles/r3_rof_variants.txt), beyond the 1e-5 parity bar;  4: refined v_rsq / v_rcp (no better than 3);
-//         1: per-voxel kernel (independent implementation)
+//            steps (rof_eval FAST = 3): bit-identical to the oracle, 3.4 ms per 1024^3 iteration.
+// dev flavour: 2 = the same roundings through the compiler's IEEE sqrt / divide expansions (independent check, 4.4 ms);
+//              3 = relaxed arithmetic (float32 sum + v_rsq_f32, 2.85 ms) -- measurement only: the D normalisation has a gain
+//              of ~1e4 on noise-dominated data, where one-ulp differences grow to 2.5e-5 .. 4.5e-5 after 60 iterations
+//              (profiles/r3_rof_variants.txt), beyond the 1e-5 parity bar;  4 = refined v_rsq / v_rcp (no better than 3);
+//              1 = per-voxel kernel (independent implementation)
 template <int ND, bool HALF>
 int rof_zmarch_dispatch(const RofArgs &a, int variant, hipStream_t st)
 {
-    int rc = variant == 4 ? rof_zmarch_launch<ND, HALF, 2, 8, 2, 2>(a, st)
-             : variant == 3 ? rof_zmarch_launch<ND, HALF, 1, 8, 2, 2>(a, st)
-             : variant == 2 ? rof_zmarch_launch<ND, HALF, 0, 8, 2, 2>(a, st)
-                            : rof_zmarch_launch<ND, HALF, 3, 8, 2, 2>(a, st);
+    int rc;
+#if TOMO_DEV
+    if (variant == 4) rc = rof_zmarch_launch<ND, HALF, 2, 8, 2, 2>(a, st);
+    else if (variant == 3) rc = rof_zmarch_launch<ND, HALF, 1, 8, 2, 2>(a, st);
+    else if (variant == 2) rc = rof_zmarch_launch<ND, HALF, 0, 8, 2, 2>(a, st);
+    else
+#endif
+    rc = rof_zmarch_launch<ND, HALF, 3, 8, 2, 2>(a, st);
+    (void)variant;
     if (rc != TOMO_OK) return rc;
     TOMO_LAUNCH_CHECK();
     return TOMO_OK;
@@ -614,21 +664,23 @@ int rof_iter(const RofArgs &a, int nd, int half, hipStream_t st)
 {
     const int nout = a.out_end - a.out_begin;
     if (nout <= 0) return TOMO_OK;
-    if (g_variant_roftv != 1) {  // z-march (default); variant 1 = per-voxel kernel below
-        const int v = g_variant_roftv;
-        if (nd == 3) return half ? rof_zmarch_dispatch<3, true>(a, v, st) : rof_zmarch_dispatch<3, false>(a, v, st);
-        return half ? rof_zmarch_dispatch<2, true>(a, v, st) : rof_zmarch_dispatch<2, false>(a, v, st);
+#if TOMO_DEV
+    if (g_variant_roftv == 1) {  // per-voxel kernel
+        dim3 grid(ceil_div(a.dx, 256), a.dy, nout);
+        if (nd == 3) {
+            if (half) rof_pervoxel_kernel<3, true><<<grid, 256, 0, st>>>(a);
+            else rof_pervoxel_kernel<3, false><<<grid, 256, 0, st>>>(a);
+        } else {
+            if (half) rof_pervoxel_kernel<2, true><<<grid, 256, 0, st>>>(a);
+            else rof_pervoxel_kernel<2, false><<<grid, 256, 0, st>>>(a);
+        }
+        TOMO_LAUNCH_CHECK();
+        return TOMO_OK;
     }
-    dim3 grid(ceil_div(a.dx, 256), a.dy, nout);
-    if (nd == 3) {
-        if (half) rof_pervoxel_kernel<3, true><<<grid, 256, 0, st>>>(a);
-        else rof_pervoxel_kernel<3, false><<<grid, 256, 0, st>>>(a);
-    } else {
-        if (half) rof_pervoxel_kernel<2, true><<<grid, 256, 0, st>>>(a);
-        else rof_pervoxel_kernel<2, false><<<grid, 256, 0, st>>>(a);
-    }
-    TOMO_LAUNCH_CHECK();
-    return TOMO_OK;
+#endif
+    const int v = g_variant_roftv;
+    if (nd == 3) return half ? rof_zmarch_dispatch<3, true>(a, v, st) : rof_zmarch_dispatch<3, false>(a, v, st);
+    return half ? rof_zmarch_dispatch<2, true>(a, v, st) : rof_zmarch_dispatch<2, false>(a, v, st);
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -661,7 +713,8 @@ extern "C" size_t tomo_roftv_scratch_bytes(int dx, int dy, int dz, int nd)
 
 extern "C" int tomo_pdtv_iters_per_launch(int half)
 {
-    return g_variant_pdtv == 1 ? 1 : pd_iters_per_launch(g_variant_pdtv, half);
+    (void)half;
+    return pd_iters_per_launch(g_variant_pdtv);
 }
 
 extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx, int dy, int dz, int nd,
@@ -700,8 +753,10 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
     // 3D volumes run several iterations per launch (K = 3 or 2, see pd_multi_launch) while that many remain, then
     // single iterations; variant 1 keeps one iteration per launch (independent implementation)
     const int v = g_variant_pdtv;
-    // a fused launch of k iterations marches k planes ahead of its output: volumes thinner than that take fewer per launch
-    const int kmax = (nd == 3 && v != 1) ? std::min(pd_iters_per_launch(v, half), dz) : 1;
+    // a fused launch of k iterations marches k planes ahead of its output: volumes thinner than that take fewer per launch.
+    // 2D images (round 4): k iterations per launch with the rows of a tile in registers (pd_rows2d.inl), any k <= 3
+    const bool rows2d = (nd == 2 && v != 1);
+    const int kmax = nd == 3 ? std::min(pd_iters_per_launch(v), dz) : pd_iters_per_launch(v);
     // cut `remaining` into launches of kmax / 2 / 1 iterations with as few single-iteration launches as possible
     // (4 = 2 + 2, 7 = 3 + 2 + 2: a single iteration costs 1.7x an iteration of a fused launch)
     auto step_of = [&](int remaining) {
@@ -723,17 +778,20 @@ extern "C" int tomo_pdtv(int device, const float *in_dev, float *out_dev, int dx
         const bool last = (it + step == iters);
         a.u_out = (last && out_dev != in_dev) ? out_dev : U[ob];
         for (int c = 0; c < 3; ++c) { a.p_in[c] = P[ib][c]; a.p_out[c] = P[ob][c]; }
-        const bool xk = (step == 3);  // pd_zmarch_xk launches understand the two flags below
+        const bool flags = (step == 3 && nd == 3) || rows2d;  // launches that understand the two flags below
         if (it == 0) {
-            if (xk) a.p_in_zero = 1;
+            if (flags) a.p_in_zero = 1;
             else for (int c = 0; c < nd; ++c) TOMO_HIP(hipMemsetAsync(P[ib][c], 0, pb, st));
         }
-        if (last && xk) a.p_out_skip = 1;
+        if (last && flags) a.p_out_skip = 1;
         a.dx = dx; a.dy = dy; a.planes = dz; a.out_begin = 0; a.out_end = dz;
         a.first_is_edge = 1; a.last_is_edge = 1;
         a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = dz;
+#if TOMO_DEV
         a.probe = g_probe;
-        if (pair) rc = half ? pd_multi_launch<__half>(a, step, methodTV, nonneg, v, st) : pd_multi_launch<float>(a, step, methodTV, nonneg, v, st);
+#endif
+        if (rows2d) rc = half ? pd_2d_launch<__half>(a, step, methodTV, nonneg, v, st) : pd_2d_launch<float>(a, step, methodTV, nonneg, v, st);
+        else if (pair) rc = half ? pd_multi_launch<__half>(a, step, methodTV, nonneg, v, st) : pd_multi_launch<float>(a, step, methodTV, nonneg, v, st);
         else rc = pd_iter(a, nd, methodTV, nonneg, half, st);
         if (rc != TOMO_OK) return rc;
         cset = ob;
@@ -809,10 +867,10 @@ extern "C" int tomo_pdtv_multi_slab_range(int device, const float *in_dev, const
     a.sigma = sigma; a.tau = tau; a.lt = lt; a.theta = theta; a.zchunk = z_end - z_begin;
     hipStream_t st = as_stream(stream);
     tomo_prof_scope prof(PROF_PDTV, st, 1);
-    // slabs always run the per-wave-halo kernels: shipped arithmetic (0), relaxed for both dual types (3), else exact;
-    // an exact three-iteration launch is variant 21
-    int v = (g_variant_pdtv == 0 || g_variant_pdtv == 3 || g_variant_pdtv == 22) ? g_variant_pdtv : 2;
-    if (k == 3 && v == 2) v = 21;
+    // fused slab launches follow the variant's arithmetic; the dev variants without a fused form of their own (1: per-voxel,
+    // 2: two iterations per launch) run the compiler-IEEE build of the tiling asked for
+    int v = g_variant_pdtv;
+    if (v == 1 || v == 2) v = (k == 3) ? 21 : 2;
     return half ? pd_multi_launch<__half>(a, k, methodTV, nonneg, v, st) : pd_multi_launch<float>(a, k, methodTV, nonneg, v, st);
 }
 

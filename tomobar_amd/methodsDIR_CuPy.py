@@ -65,6 +65,7 @@ class RecToolsDIRCuPy:
         Keyword Args: ``data_axes_labels_order`` -- axis order of the OUTPUT; the reference applies
         ``_data_dims_swapper(projected, value, ["detY", "angles", "detX"])`` (:84-88), so does this (the swapped
         result is returned C-contiguous)."""
+        given = data
         data = ops.to_device(data, self.Atools.device_index)
         flat = self.is2d and data.dim() == 2
         projected = self.Atools._forwprojCuPy(data.unsqueeze(0) if flat else data)
@@ -74,16 +75,17 @@ class RecToolsDIRCuPy:
         if labels is not None:
             projected = ops.contiguous(_data_dims_swapper(projected, labels,
                                                           ["angles", "detX"] if flat else ["detY", "angles", "detX"]))
-        return projected
+        return ops.like(projected, given)
 
     def BACKPROJ(self, data, **kwargs):
         """Back projection of ``[detY, angles, detX]`` data (methodsDIR_CuPy.py:92-112).  The input is made
         contiguous first; the reference hands ASTRA the base pointer of a strided view (astra_base.py:533-535)."""
+        given = data
         flat = self.is2d and ops.to_device(data, self.Atools.device_index).dim() == 2
         data = self._lift(data, kwargs.get("data_axes_labels_order"), ["detY", "angles", "detX"], ["angles", "detX"])
         data = _apply_horiz_detector_padding(ops.contiguous(data), self.Atools.detectors_x_pad, True)
         rec = self.Atools._backprojCuPy(data)
-        return rec.squeeze(0) if flat else rec
+        return ops.like(rec.squeeze(0) if flat else rec, given)
 
     def FBP(self, data, **kwargs):
         """Filtered back projection with the sinc-ramp filter (reference: methodsDIR_CuPy.py:114-150).
@@ -99,8 +101,8 @@ class RecToolsDIRCuPy:
         if data.dtype != torch.float32 or data.dim() != 3:
             raise ValueError("FBP expects a float32 3D array")
         data = _apply_horiz_detector_padding(data, self.Atools.detectors_x_pad, True)
-        if isinstance(given, torch.Tensor) and data.data_ptr() == given.data_ptr():
-            data = data.clone()  # the filter works in place: never overwrite the caller's array
+        if data.data_ptr() == ops.base_ptr(given):
+            data = data.clone()  # the filter works in place: never overwrite the caller's (torch or cupy) array
         na, nz, nu = data.shape
         with torch.cuda.device(data.device):
             L.check(L.lib().tomo_fbp_filter(data.device.index, ops.ptr(data), na * nz, nu, float(cutoff),
@@ -109,7 +111,7 @@ class RecToolsDIRCuPy:
         del data
         rec = self.Atools._backprojCuPy(sino)
         rec = check_kwargs(rec, cupyrun=True, recon_mask_radius=kwargs.get("recon_mask_radius"))
-        return rec.squeeze(0) if flat else rec
+        return ops.like(rec.squeeze(0) if flat else rec, given)
 
     def FOURIER_INV(self, data, **kwargs):
         """Fourier direct inversion on unequally spaced grids (reference: methodsDIR_CuPy.py:152-447, after V. Nikitin's
@@ -173,6 +175,7 @@ class RecToolsDIRCuPy:
                 shape = tuple(shape[list(labels).index(k)] for k in ["detY", "angles", "detX"])
             nz, nproj, data_n = shape
         else:
+            given = data
             data = ops.to_device(data, self.Atools.device_index)
             if labels is not None:
                 data = _data_dims_swapper(data, labels, ["detY", "angles", "detX"])
@@ -233,4 +236,4 @@ class RecToolsDIRCuPy:
             L.check(L.lib().tomo_fourier_inv(data.device.index, ops.ptr(data), ops.ptr(out), nz_even, nz, nproj, raw_n, n, ne,
                                              unpad_m, size, w.ctypes.data, theta.ctypes.data, int(m), float(mu),
                                              int(center_size), ops.stream_ptr(data)))
-        return check_kwargs(out, cupyrun=True, recon_mask_radius=kwargs.get("recon_mask_radius"))
+        return ops.like(check_kwargs(out, cupyrun=True, recon_mask_radius=kwargs.get("recon_mask_radius")), given)

@@ -97,6 +97,7 @@ class RecToolsIRCuPy:
         return v
 
     def _prepare_data(self, _data_, _algorithm_, _regularisation_, method_run):
+        self._given = _data_.get("projection_data") if isinstance(_data_, dict) else None  # decides the array library of the result
         d, a, r = dicts_check(self, _data_, _algorithm_, _regularisation_, method_run=method_run)
         d["projection_data"] = _apply_horiz_detector_padding(d["projection_data"], self.Atools.detectors_x_pad, True)
         expect = self.Atools.sino_shape(None)
@@ -108,9 +109,11 @@ class RecToolsIRCuPy:
         return d, a, r
 
     def _finalise(self, x, _algorithm_):
+        given = getattr(self, "_given", None)
+        self._given = None
         if self.objsize_user_given is not None:
-            return perform_recon_crop(x, self.objsize_user_given)  # cropped result is not masked (:477-478)
-        return check_kwargs(x, cupyrun=True, recon_mask_radius=_algorithm_["recon_mask_radius"])
+            return ops.like(perform_recon_crop(x, self.objsize_user_given), given)  # cropped result is not masked (:477-478)
+        return ops.like(check_kwargs(x, cupyrun=True, recon_mask_radius=_algorithm_["recon_mask_radius"]), given)
 
     def __common_initialisation(self, _data_, _algorithm_, _regularisation_, method_run):
         d, a, r = self._prepare_data(_data_, _algorithm_, _regularisation_, method_run)

@@ -22,13 +22,39 @@ def _require_gpu(device_index: int) -> torch.device:
 
 
 def to_device(x, device_index: int = 0) -> torch.Tensor:
-    """numpy / torch / __cuda_array_interface__ object -> float32-preserving device tensor (no dtype change)."""
+    """numpy / torch / cupy (DLPack or __cuda_array_interface__) object -> float32-preserving device tensor (no dtype
+    change, no copy for arrays that already live on the device)."""
     dev = _require_gpu(device_index)
     if isinstance(x, torch.Tensor):
         return x.to(dev)
     if isinstance(x, np.ndarray):
         return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    if is_cupy(x) and hasattr(x, "__dlpack__"):
+        return torch.from_dlpack(x).to(dev)
     return torch.as_tensor(x, device=dev)
+
+
+def is_cupy(x) -> bool:
+    return type(x).__module__.split(".")[0] == "cupy"
+
+
+def base_ptr(x):
+    """Device address of a torch / cupy array (None for anything else): used to detect zero-copy views of caller memory."""
+    if isinstance(x, torch.Tensor):
+        return x.data_ptr()
+    if is_cupy(x):
+        return int(x.data.ptr)
+    return None
+
+
+def like(result, given):
+    """`result` (a device tensor) in the array library the caller used for `given`: the reference's classes return
+    ``cupy.ndarray`` (methodsIR_CuPy.py:484), so a caller that hands CuPy arrays in gets CuPy arrays back (zero-copy through
+    DLPack) wherever CuPy-on-ROCm is installed; every other caller gets the ``torch.Tensor``.  CuPy is never required."""
+    if isinstance(result, torch.Tensor) and is_cupy(given):
+        import cupy
+        return cupy.from_dlpack(result)
+    return result
 
 
 def stream_ptr(t: torch.Tensor):

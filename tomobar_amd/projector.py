@@ -111,8 +111,9 @@ class HipTools3D:
             raise ValueError("The CoR must be a scalar, a vector [angles] or an array [angles, 2]")
 
         self._device = ops._require_gpu(self.device_index)
+        self._lib = L.lib()   # the context lives in THIS library: every later call goes to the same handle (see _lib.use_flavour)
         handle = C.c_void_p()
-        L.check(L.lib().tomo_ctx_create(
+        self._chk(self._lib.tomo_ctx_create(
             self.device_index, self.nz, self.n, self.nu, self.na,
             self.angles_vec.ctypes.data_as(C.POINTER(C.c_double)), cor_arr.ctypes.data_as(C.POINTER(C.c_double)),
             stride, self.ordsub_number, L.FLAG_LERP8 if lerp8 else 0, C.byref(handle)))
@@ -123,9 +124,9 @@ class HipTools3D:
                          "option": {"WindowMinX": -self.n / 2, "WindowMaxX": self.n / 2,
                                     "WindowMinY": -self.n / 2, "WindowMaxY": self.n / 2,
                                     "WindowMinZ": -self.nz / 2, "WindowMaxZ": self.nz / 2}}
-        self.NumbProjBins = L.lib().tomo_ctx_num_bins(self._ctx)
+        self.NumbProjBins = self._lib.tomo_ctx_num_bins(self._ctx)
         table = np.zeros((self.ordsub_number, self.NumbProjBins), dtype=np.int64)
-        L.check(L.lib().tomo_ctx_newind_table(self._ctx, table.ctypes.data_as(C.POINTER(C.c_int64))))
+        self._chk(self._lib.tomo_ctx_newind_table(self._ctx, table.ctypes.data_as(C.POINTER(C.c_int64))))
         self.newInd_Vec = table
         if self.ordsub_number == 1:
             self.proj_geom = self._proj_geom(np.arange(self.na))
@@ -147,7 +148,7 @@ class HipTools3D:
         return ind
 
     def subset_size(self, os_index) -> int:
-        return L.lib().tomo_ctx_subset_size(self._ctx, -1 if os_index is None else int(os_index))
+        return self._lib.tomo_ctx_subset_size(self._ctx, -1 if os_index is None else int(os_index))
 
     def vol_shape(self):
         return (self.nz, self.n, self.n)
@@ -201,7 +202,7 @@ class HipTools3D:
         if out is None:
             out = torch.empty_like(sino)
         with torch.cuda.device(self._device):
-            L.check(L.lib().tomo_shift_rows(ops.ptr(sino), ops.ptr(out), self.nz, int(sino.shape[1]), self.nu,
+            self._chk(self._lib.tomo_shift_rows(ops.ptr(sino), ops.ptr(out), self.nz, int(sino.shape[1]), self.nu,
                                             ops.ptr(tabs[key]), float(sign), ops.stream_ptr(sino)))
         return out
 
@@ -217,10 +218,10 @@ class HipTools3D:
         if self._vshift is not None:
             tmp = torch.empty_like(out)
             with torch.cuda.device(self._device):
-                L.check(L.lib().tomo_fp3d(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(tmp), ops.stream_ptr(vol)))
+                self._chk(self._lib.tomo_fp3d(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(tmp), ops.stream_ptr(vol)))
             return self._shift_rows(tmp, os_index, 1.0, out)
         with torch.cuda.device(self._device):
-            L.check(L.lib().tomo_fp3d(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(out), ops.stream_ptr(vol)))
+            self._chk(self._lib.tomo_fp3d(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(out), ops.stream_ptr(vol)))
         return out
 
     def backward(self, sino, os_index=None, out=None):
@@ -228,7 +229,7 @@ class HipTools3D:
         if out is None:
             out = torch.empty(self.vol_shape(), dtype=torch.float32, device=self._device)
         with torch.cuda.device(self._device):
-            L.check(L.lib().tomo_bp3d(self._ctx, self._sub(os_index), ops.ptr(sino), ops.ptr(out), ops.stream_ptr(sino)))
+            self._chk(self._lib.tomo_bp3d(self._ctx, self._sub(os_index), ops.ptr(sino), ops.ptr(out), ops.stream_ptr(sino)))
         return out
 
     # fused forms used by the FISTA / ADMM drivers (buffers validated by the drivers)
@@ -239,13 +240,13 @@ class HipTools3D:
             ax = self.forward(vol, os_index)
             src = self._src_table(os_index)
             with torch.cuda.device(self._device):
-                L.check(L.lib().tomo_sino_residual(ops.ptr(ax), ops.ptr(b), ops.ptr(w), ops.ptr(src), self.nz,
+                self._chk(self._lib.tomo_sino_residual(ops.ptr(ax), ops.ptr(b), ops.ptr(w), ops.ptr(src), self.nz,
                                                    int(src.numel()), self.na, self.nu, int(gathered), L.FID[fidelity],
                                                    ops.ptr(out),
                                                    ops.stream_ptr(vol)))
             return out
         with torch.cuda.device(self._device):
-            L.check(L.lib().tomo_fp3d_residual(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(b),
+            self._chk(self._lib.tomo_fp3d_residual(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(b),
                                                ops.ptr(w), int(gathered), L.FID[fidelity], ops.ptr(out),
                                                ops.stream_ptr(vol)))
         return out
@@ -265,7 +266,7 @@ class HipTools3D:
         if self._vshift is not None:
             raise ValueError("the Group-Huber ring term is not supported together with a vertical CoR component")
         with torch.cuda.device(self._device):
-            L.check(L.lib().tomo_fp3d_residual_ring(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(b), ops.ptr(r_x),
+            self._chk(self._lib.tomo_fp3d_residual_ring(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(b), ops.ptr(r_x),
                                                     float(accelerate), ops.ptr(out), ops.stream_ptr(vol)))
         return out
 
@@ -273,69 +274,72 @@ class HipTools3D:
         """r_out = r_x - l_inv * sum_angles(res); afterwards res *= w_s in place when PWLS weights are given."""
         src = self._src_table(os_index)
         with torch.cuda.device(self._device):
-            L.check(L.lib().tomo_ring_gh_reduce(ops.ptr(res), ops.ptr(w), ops.ptr(src), self.nz, int(src.numel()), self.na,
+            self._chk(self._lib.tomo_ring_gh_reduce(ops.ptr(res), ops.ptr(w), ops.ptr(src), self.nz, int(src.numel()), self.na,
                                                 self.nu, ops.ptr(r_x), float(l_inv), ops.ptr(r_out), ops.stream_ptr(res)))
 
     def swls_apply(self, res, w, beta, os_index):
         src = self._src_table(os_index)
         with torch.cuda.device(self._device):
-            L.check(L.lib().tomo_swls_apply(ops.ptr(res), ops.ptr(w), ops.ptr(src), self.nz, int(src.numel()), self.na,
+            self._chk(self._lib.tomo_swls_apply(ops.ptr(res), ops.ptr(w), ops.ptr(src), self.nz, int(src.numel()), self.na,
                                             self.nu, float(beta), ops.stream_ptr(res)))
 
     def ring_update(self, r, r_old, r_x, lam, beta):
         with torch.cuda.device(self._device):
-            L.check(L.lib().tomo_ring_gh_update(ops.ptr(r), ops.ptr(r_old), ops.ptr(r_x), float(lam), float(beta),
+            self._chk(self._lib.tomo_ring_gh_update(ops.ptr(r), ops.ptr(r_old), ops.ptr(r_x), float(lam), float(beta),
                                                 r.numel(), ops.stream_ptr(r)))
 
     def momentum(self, x, x_old, x_t, beta):
         """x_t = x + beta (x - x_old), leaving the in-plane transposed x_t in the context for the next forward
         projection of x_t (which then skips its transpose pass)."""
         with torch.cuda.device(self._device):
-            L.check(L.lib().tomo_momentum_transposed(self._ctx, ops.ptr(x), ops.ptr(x_old), ops.ptr(x_t), float(beta),
+            self._chk(self._lib.tomo_momentum_transposed(self._ctx, ops.ptr(x), ops.ptr(x_old), ops.ptr(x_t), float(beta),
                                                      ops.stream_ptr(x)))
 
     def invalidate(self):
         """Drop the one-shot transposed copy ``momentum`` may have left in the context (see tomo_ctx_invalidate)."""
-        L.check(L.lib().tomo_ctx_invalidate(self._ctx))
+        self._chk(self._lib.tomo_ctx_invalidate(self._ctx))
 
     def grad_step(self, res, x_t, x_out, l_inv, nonneg, os_index):
         res = self._adjoint_in(res, os_index)
         with torch.cuda.device(self._device):
-            L.check(L.lib().tomo_bp3d_fista(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(x_t), ops.ptr(x_out),
+            self._chk(self._lib.tomo_bp3d_fista(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(x_t), ops.ptr(x_out),
                                             float(l_inv), int(bool(nonneg)), ops.stream_ptr(x_t)))
 
     def grad_step_momentum(self, res, x_t, x_old_then_x, l_inv, beta, nonneg, os_index):
         res = self._adjoint_in(res, os_index)
         with torch.cuda.device(self._device):
-            L.check(L.lib().tomo_bp3d_fista_momentum(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(x_t),
+            self._chk(self._lib.tomo_bp3d_fista_momentum(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(x_t),
                                                      ops.ptr(x_old_then_x), float(l_inv), float(beta),
                                                      int(bool(nonneg)), ops.stream_ptr(x_t)))
 
     def admm_z_update(self, res, z, x, u, zu_out, tau, rho, relax_on, one_minus_alpha, alpha, nonneg, os_index):
         res = self._adjoint_in(res, os_index)
         with torch.cuda.device(self._device):
-            L.check(L.lib().tomo_bp3d_admm(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(z), ops.ptr(x),
+            self._chk(self._lib.tomo_bp3d_admm(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(z), ops.ptr(x),
                                            ops.ptr(u), ops.ptr(zu_out), float(tau), float(rho), int(bool(relax_on)),
                                            float(one_minus_alpha), float(alpha), int(bool(nonneg)), ops.stream_ptr(z)))
 
     def angle_table(self, os_index=None):
         n = self.subset_size(os_index)
         tab = (L.AngleRecord * max(n, 1))()
-        L.check(L.lib().tomo_ctx_angle_table(self._ctx, self._sub(os_index), tab, max(n, 1)))
+        self._chk(self._lib.tomo_ctx_angle_table(self._ctx, self._sub(os_index), tab, max(n, 1)))
         return tab, n
 
     def kernel_path(self, op: str = "fp") -> str:
         """Which kernel form the last forward ("fp") / back ("bp") projection of this object took (diagnostics)."""
-        return L.lib().tomo_ctx_kernel_path(self._ctx, op.encode()).decode()
+        return self._lib.tomo_ctx_kernel_path(self._ctx, op.encode()).decode()
+
+    def _chk(self, rc):
+        L.check(rc, self._lib)
 
     def release_scratch(self):
-        L.check(L.lib().tomo_ctx_release_scratch(self._ctx))
+        self._chk(self._lib.tomo_ctx_release_scratch(self._ctx))
 
     def __del__(self):
         ctx = getattr(self, "_ctx", None)
         if ctx:
             try:
-                L.lib().tomo_ctx_destroy(ctx)
+                self._lib.tomo_ctx_destroy(ctx)
             except Exception:
                 pass
             self._ctx = None

@@ -54,9 +54,9 @@ def _prepare(data, gpu_id: int):
     return ops.contiguous(data), is2d, axis
 
 
-def _finish(result, is2d, axis, orig_shape, out):
+def _finish(result, is2d, axis, orig_shape, out, given=None):
     result = result.unsqueeze(axis) if is2d else result
-    return result if out is None else out.view(orig_shape)
+    return ops.like(result, given) if out is None else out.view(orig_shape)
 
 
 def ROF_TV_cupy(data, regularisation_parameter: float = 1e-05, iterations: int = 3000,
@@ -71,7 +71,7 @@ def ROF_TV_cupy(data, regularisation_parameter: float = 1e-05, iterations: int =
     res = torch.empty_like(d) if out is None else out.view(d.shape)
     ops.roftv(d, res, np.float32(regularisation_parameter), np.float32(time_marching_parameter), iterations,
               half_precision)
-    return _finish(res, is2d, axis, orig_shape, out)
+    return _finish(res, is2d, axis, orig_shape, out, data)
 
 
 def PD_TV_cupy(data, regularisation_parameter: float = 1e-05, iterations: int = 1000, methodTV: int = 0,
@@ -87,7 +87,7 @@ def PD_TV_cupy(data, regularisation_parameter: float = 1e-05, iterations: int = 
     lt = np.float32(tau / regularisation_parameter)
     res = torch.empty_like(d) if out is None else out.view(d.shape)
     ops.pdtv(d, res, sigma, tau, lt, theta, iterations, methodTV, nonneg, half_precision)
-    return _finish(res, is2d, axis, orig_shape, out)
+    return _finish(res, is2d, axis, orig_shape, out, data)
 
 
 def _check_if_input_2d_or_3d(data) -> Tuple[torch.Tensor, bool, int]:

@@ -5,7 +5,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from tomobar_amd import ops
+from tomobar_amd import _lib, ops
 from tomobar_amd.projector import HipTools3D
 from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
 
@@ -37,25 +37,27 @@ vol = torch.rand((NZ, N, N), device="cuda")
 sino = torch.rand((NZ, NA, N), device="cuda")
 out_v = torch.empty_like(vol)
 out_s = torch.empty_like(sino)
-for variant in (0, 2, 1):
+DEV = _lib.flavour() == "dev"   # TOMO_MI355X_FLAVOUR=dev python tools/kernel_bench.py ...: the A/B variants as well
+print(f"library flavour: {_lib.flavour()}")
+for variant in ((0, 2, 1) if DEV else (0,)):
     ops.set_variant("bp", variant)
     ms = timeit(lambda: H.backward(sino, None, out=out_v))
     print(f"BP  variant {variant}: {ms:8.3f} ms  {4*(S+V)/ms/1e6:8.1f} GB/s alg  {V*NA/ms/1e6:8.1f} GUPS")
 ops.set_variant("bp", 0)
-for variant in (0, 2, 1):
+for variant in ((0, 2, 1) if DEV else (0,)):
     ops.set_variant("fp", variant)
     ms = timeit(lambda: H.forward(vol, None, out=out_s))
     print(f"FP  variant {variant}: {ms:8.3f} ms  {4*(S+V)/ms/1e6:8.1f} GB/s alg  {V*NA/ms/1e6:8.1f} GUPS")
 ops.set_variant("fp", 0)
 IT = 10
-for variant in (0, 3, 2, 21, 22, 1):
+for variant in ((0, 3, 2, 21, 1) if DEV else (0, 3)):
     ops.set_variant("pdtv", variant)
     for half in (False, True):
         ms = timeit(lambda: PD_TV_cupy(vol, 0.01, IT, 0, 1, 12.0, 0, half, out=out_v)) / IT
         bpv = 24 if half else 36
         print(f"PD_TV v{variant} half={int(half)}: {ms:8.3f} ms/iter  {bpv*V/ms/1e6:8.1f} GB/s alg")
 ops.set_variant("pdtv", 0)
-for variant in (0, 2, 1):
+for variant in ((0, 2, 3, 1) if DEV else (0,)):
     ops.set_variant("roftv", variant)
     ms = timeit(lambda: ROF_TV_cupy(vol, 0.01, IT, 0.001, 0, False, out=out_v)) / IT
     print(f"ROF_TV v{variant}     : {ms:8.3f} ms/iter  {12*V/ms/1e6:8.1f} GB/s alg")

@@ -5,6 +5,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
+if os.environ.get("PMC_PROBE", "0") != "0" or (len(sys.argv) > 1 and sys.argv[1].rstrip("h") in ("pdtv1", "pdtv2", "pdtv21", "bp1", "bp2")):
+    os.environ.setdefault("TOMO_MI355X_FLAVOUR", "dev")   # measurement switches / A-B variants: libtomo_mi355x_dev.so
 from tomobar_amd import ops
 from tomobar_amd.projector import HipTools3D
 from tomobar_amd.regularisersCuPy import PD_TV_cupy, ROF_TV_cupy
@@ -15,7 +17,8 @@ NZ = int(sys.argv[3]) if len(sys.argv) > 3 else N
 NA = int(sys.argv[4]) if len(sys.argv) > 4 else 75
 vol = torch.rand((NZ, N, N), device="cuda")
 out = torch.empty_like(vol)
-ops.set_variant("probe", int(os.environ.get("PMC_PROBE", "0")))   # measurement switches (tools/pd_halo_probe.py)
+if os.environ.get("PMC_PROBE", "0") != "0":
+    ops.set_variant("probe", int(os.environ["PMC_PROBE"]))   # measurement switches (tools/pd_halo_probe.py)
 if what.startswith("pdtv"):
     ops.set_variant("pdtv", int(what[4:].rstrip("h")))
     PD_TV_cupy(vol, 0.01, int(os.environ.get("PMC_PD_ITERS", "6")), 0, 1, 12.0, 0, what.endswith("h"), out=out)  # 3 + 3 (shipped f32) or 2 + 2 + 2; 9 = first (zero duals) + middle + last (no dual stores) launch

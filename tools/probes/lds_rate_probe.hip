@@ -12,10 +12,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 #define RD(r, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(r) : "v"(addr))
 
-// MODE 0: reads only; 1: + 2 v_pk_fma_f32 per read (BP mix), consuming the PREVIOUS batch (so no wait inside a batch)
+// MODE 0: reads only; 1: + 2 v_pk_fma_f32 per read, consuming the PREVIOUS batch (so no wait inside a batch);
+// MODE 2: + 2 v_pk_fma_f32 + 2 plain VALU (v_fmac_f32) per read = the back projector's real ratio, 4.1 VALU per LDS
+//         instruction (SQ_INSTS_VALU 2.90e9 / SQ_INSTS_LDS 7.03e8, profiles/r4b_fp_lane_permutation_ab.txt)
 // STRIDE16: lane stride in 16-B slots x 100 (100 = unit stride, 141 = FP's worst case)
 #define USE(r) acc0 = __builtin_elementwise_fma(w, v2f{r.x, r.y}, acc0); acc1 = __builtin_elementwise_fma(w, v2f{r.z, r.w}, acc1);
 #define USE2(r) acc2 = __builtin_elementwise_fma(w, v2f{r.x, r.y}, acc2); acc3 = __builtin_elementwise_fma(w, v2f{r.z, r.w}, acc3);
+#define EXTRA() if (MODE == 2) { sc0 = __builtin_fmaf(sc0, a, sc1); sc1 = __builtin_fmaf(sc1, a, sc0); }
 template <int MODE, int STRIDE100, int THREADS>
 __global__ __launch_bounds__(THREADS) void probe(float *out, int iters, float a)
 {
@@ -27,15 +30,16 @@ __global__ __launch_bounds__(THREADS) void probe(float *out, int iters, float a)
     v4f r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
     v2f acc0 = {0, 0}, acc1 = {0, 0}, acc2 = {0, 0}, acc3 = {0, 0};
     const v2f w = {a, a};
+    float sc0 = a, sc1 = 2.0f * a;
     r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = r8 = r9 = r10 = r11 = r12 = r13 = r14 = r15 = v4f{0, 0, 0, 0};
     for (int it = 0; it < iters; ++it) {
-        if (MODE == 1) {
+        if (MODE >= 1) {
             // batch A in flight while the packed FMAs consume batch B, then the other way round (16 reads per iteration)
             RD(r0, 0); RD(r1, 2048); RD(r2, 4096); RD(r3, 6144); RD(r4, 8192); RD(r5, 10240); RD(r6, 12288); RD(r7, 14336);
-            USE(r8) USE2(r9) USE(r10) USE2(r11) USE(r12) USE2(r13) USE(r14) USE2(r15)
+            USE(r8) EXTRA() USE2(r9) EXTRA() USE(r10) EXTRA() USE2(r11) EXTRA() USE(r12) EXTRA() USE2(r13) EXTRA() USE(r14) EXTRA() USE2(r15) EXTRA()
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             RD(r8, 16384); RD(r9, 18432); RD(r10, 20480); RD(r11, 22528); RD(r12, 24576); RD(r13, 26624); RD(r14, 28672); RD(r15, 30720);
-            USE(r0) USE2(r1) USE(r2) USE2(r3) USE(r4) USE2(r5) USE(r6) USE2(r7)
+            USE(r0) EXTRA() USE2(r1) EXTRA() USE(r2) EXTRA() USE2(r3) EXTRA() USE(r4) EXTRA() USE2(r5) EXTRA() USE(r6) EXTRA() USE2(r7) EXTRA()
         } else {
             RD(r0, 0); RD(r1, 2048); RD(r2, 4096); RD(r3, 6144); RD(r4, 8192); RD(r5, 10240); RD(r6, 12288); RD(r7, 14336);
             RD(r8, 16384); RD(r9, 18432); RD(r10, 20480); RD(r11, 22528); RD(r12, 24576); RD(r13, 26624); RD(r14, 28672); RD(r15, 30720);
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(THREADS) void probe(float *out, int iters, float a)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     v4f s = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + r8 + r9 + r10 + r11 + r12 + r13 + r14 + r15;
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y + s.z + s.w + acc0.x + acc0.y + acc1.x + acc1.y + acc2.x + acc2.y + acc3.x + acc3.y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y + s.z + s.w + acc0.x + acc0.y + acc1.x + acc1.y + acc2.x + acc2.y + acc3.x + acc3.y + sc0 + sc1;
 }
 
 template <int MODE, int STRIDE100, int THREADS>
@@ -79,7 +83,8 @@ int main()
     printf("device: %s  CUs=%d  sclk(max)=%.2f GHz  (clk figures assume the max clock; the sustained clock under LDS load is lower)\n",
            prop.name, prop.multiProcessorCount, ghz);
 #define ALL(T) run<0, 100, T>("reads only, stride 1", 1, ghz); run<0, 141, T>("reads only, stride 1.41", 1, ghz); \
-               run<1, 100, T>("read + 2 v_pk_fma (BP mix), s1", 1, ghz); run<1, 141, T>("read + 2 v_pk_fma, stride 1.41", 1, ghz);
+               run<1, 100, T>("read + 2 v_pk_fma, stride 1", 1, ghz); run<1, 141, T>("read + 2 v_pk_fma, stride 1.41", 1, ghz); \
+               run<2, 100, T>("read + 2 v_pk_fma + 2 VALU (BP mix)", 1, ghz);
     ALL(256) ALL(512) ALL(768) ALL(1024)
     return 0;
 }

@@ -16,6 +16,11 @@ __device__ __forceinline__ float mk_recip(float q)
     y = fmaf(fmaf(-q, y, 1.0f), y, y);
     return fmaf(fmaf(-q, y, 1.0f), y, y);
 }
+__device__ __forceinline__ float mk_recip1(float q)  // ONE Newton step: is it already correctly rounded on this hardware?
+{
+    float y = __builtin_amdgcn_rcpf(q);
+    return fmaf(fmaf(-q, y, 1.0f), y, y);
+}
 __device__ __forceinline__ float mk_div(float nom, float q)
 {
     float y = __builtin_amdgcn_rcpf(q);
@@ -33,12 +38,13 @@ __global__ void rcp_allones(float *raw, float *want)
     want[k] = 1.0f / q;
 }
 
+template <int STEPS>
 __global__ void recip_all(uint32_t lo, uint32_t hi, unsigned long long *bad, uint32_t *first)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t b = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= hi; b += stride) {
         const float q = __uint_as_float((uint32_t)b);
-        const float a = mk_recip(q), w = 1.0f / q;
+        const float a = STEPS == 2 ? mk_recip(q) : mk_recip1(q), w = 1.0f / q;
         if (__float_as_uint(a) != __float_as_uint(w))
             if (atomicAdd(bad, 1ULL) < 8) first[atomicAdd(first + 8, 1u) & 7] = (uint32_t)b;
     }
@@ -82,10 +88,16 @@ int main()
            exact, low, other, hr[127], hw[127]);
     hipMemset(bad, 0, 8); hipMemset(first, 0, 64);
     uint32_t lo, hi; float flo = 0x1p-100f, fhi = 0x1p100f; memcpy(&lo, &flo, 4); memcpy(&hi, &fhi, 4);
-    recip_all<<<8192, 256>>>(lo, hi, bad, first);
     unsigned long long nb, nc; uint32_t f[9];
+    recip_all<2><<<8192, 256>>>(lo, hi, bad, first);
     hipMemcpy(&nb, bad, 8, hipMemcpyDeviceToHost); hipMemcpy(f, first, 36, hipMemcpyDeviceToHost);
     printf("mk_recip (v_rcp + 2 Newton steps): %u inputs in [2^-100, 2^100], mismatches vs 1.0f / q: %llu", hi - lo + 1, nb);
+    for (int i = 0; i < 4 && (unsigned long long)i < nb; ++i) { float v; memcpy(&v, &f[i], 4); printf("  q=%a", v); }
+    printf("\n");
+    hipMemset(bad, 0, 8); hipMemset(first, 0, 64);
+    recip_all<1><<<8192, 256>>>(lo, hi, bad, first);
+    hipMemcpy(&nb, bad, 8, hipMemcpyDeviceToHost); hipMemcpy(f, first, 36, hipMemcpyDeviceToHost);
+    printf("          (v_rcp + 1 Newton step ): %u inputs in [2^-100, 2^100], mismatches vs 1.0f / q: %llu", hi - lo + 1, nb);
     for (int i = 0; i < 4 && (unsigned long long)i < nb; ++i) { float v; memcpy(&v, &f[i], 4); printf("  q=%a", v); }
     printf("\n");
     hipMemset(bad, 0, 8); hipMemset(count, 0, 8); hipMemset(ff, 0, 64);

@@ -43,14 +43,17 @@ def main():
     ap.add_argument("--n", type=int, default=2560, help="plane size (configs[4]: 2560)")
     ap.add_argument("--nz", type=int, default=128, help="slices of the slab the concurrent kernel works on")
     ap.add_argument("--reps", type=int, default=5)
-    args = ap.parse_args()
+    # ranks started below read their arguments from the environment: torch.distributed.run's own parser rejects options of
+    # this script that are prefixes of its own (--n)
+    args = ap.parse_args(json.loads(os.environ["TOMO_PREFLIGHT_ARGV"]) if "RANK" in os.environ and "TOMO_PREFLIGHT_ARGV" in os.environ
+                         else None)
     if "RANK" not in os.environ:
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "1")
+        env["TOMO_PREFLIGHT_ARGV"] = json.dumps(sys.argv[1:])
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__),
-               "--gpus", str(args.gpus), "--n", str(args.n), "--nz", str(args.nz), "--reps", str(args.reps)]
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)]
         sys.exit(subprocess.call(cmd, env=env))
 
     import torch

@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import statistics
 import torch
+os.environ.setdefault("TOMO_MI355X_FLAVOUR", "dev")  # A/B variants and measurement switches live in libtomo_mi355x_dev.so
 from tomobar_amd import ops
 from tomobar_amd.regularisersCuPy import ROF_TV_cupy
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024

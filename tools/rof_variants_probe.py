@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import tomo_oracle as O
+os.environ.setdefault("TOMO_MI355X_FLAVOUR", "dev")  # A/B variants and measurement switches live in libtomo_mi355x_dev.so
 from tomobar_amd import ops
 from tomobar_amd.regularisersCuPy import ROF_TV_cupy
 SH = [(6, 9, 13), (1, 20, 17), (12, 1, 70), (10, 11, 1), (8, 8, 8), (3, 5, 131), (24, 19), (20, 70, 150), (9, 40, 70), (33, 90, 200)]
