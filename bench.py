@@ -50,7 +50,8 @@ LDS_PEAK_BPS = 256.0 * 256 * 2.4e9  # same guide, LDS: ds_read_b128 256 B/clk/CU
 # source files whose content decides the HBM traffic of each kernel class (profiles/pmc_traffic.json is only valid
 # for the sources it was measured on)
 KERNEL_SOURCES = {
-    "pdtv": ["tomobar_amd/csrc/tv_kernels.hip", "tomobar_amd/csrc/pd_zmarch_xk.inl", "tomobar_amd/csrc/pd_zmarch_x2.inl", "tomobar_amd/csrc/pd_zmarch2.inl"],
+    "pdtv": ["tomobar_amd/csrc/tv_kernels.hip", "tomobar_amd/csrc/pd_zmarch_xk.inl", "tomobar_amd/csrc/pd_zmarch_x2.inl", "tomobar_amd/csrc/pd_zmarch2.inl",
+             "tomobar_amd/csrc/pd_rows2d.inl", "tomobar_amd/csrc/tomo_common.h"],
     "roftv": ["tomobar_amd/csrc/tv_kernels.hip", "tomobar_amd/csrc/rof_zmarch.inl"],
     "bp": ["tomobar_amd/csrc/proj_kernels.hip", "tomobar_amd/csrc/bp_brick.inl"],
     "fp": ["tomobar_amd/csrc/proj_kernels.hip", "tomobar_amd/csrc/fp_tiled.inl"],
@@ -105,9 +106,9 @@ def parse():
     p.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     p.add_argument("--cpu-slices", type=int, default=8)
-    p.add_argument("--relaxed-tv", action="store_true",
-                   help="PD_TV with the opt-in relaxed arithmetic (tomo_set_variant('pdtv', 3): <= 1e-5 from the default, "
-                        "which reproduces the reference's roundings); the workload string says so")
+    p.add_argument("--exact-tv", action="store_true",
+                   help="PD_TV float32 duals with the reference's rounding sequence (tomo_set_variant('pdtv', 22): bit-identical "
+                        "to the oracle, +16 %% per launch; the default is within 1e-5); the workload string says so")
     p.add_argument("--no-north-star", action="store_true",
                    help="N > 1 only: skip the extra `north_star` block (strong scaling of configs[4] when it fits)")
     if len(sys.argv) == 1 and "TOMO_BENCH_ARGV" in os.environ and "RANK" in os.environ:  # rank started by self_launch()
@@ -138,8 +139,8 @@ def apply_preset(args):
             overridden.append(key)
     if args.half:
         overridden.append("half")
-    if getattr(args, "relaxed_tv", False):
-        overridden.append("relaxed PD_TV arithmetic")
+    if getattr(args, "exact_tv", False):
+        overridden.append("PD_TV with the reference's roundings (variant 22)")
     args.overridden = overridden   # the workload string names the BASELINE config only when nothing was overridden
 
 
@@ -279,7 +280,7 @@ def measure(args, env):
     from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
     from tomobar_amd.slab import GHOST, SlabComm, check_slab_split, pd_launch_plan, slab_bounds
     lib = _lib.lib()
-    lib.tomo_set_variant(b"pdtv", 3 if getattr(args, "relaxed_tv", False) else 0)
+    lib.tomo_set_variant(b"pdtv", 22 if getattr(args, "exact_tv", False) else 0)
 
     n, na = args.n, args.angles
     if args.strong:

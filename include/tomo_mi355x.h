@@ -319,12 +319,14 @@ int tomo_fourier_inv(int device, const float *data_dev, float *out_dev, int nz, 
                      int m, float mu, int center_size, void *stream);
 
 /* kernel-variant selector (per calling host thread): name in {"bp","fp","pdtv","roftv"}; variant 0 = the default of every
- * class.  The shipped library accepts exactly one other value: "pdtv" 3 = relaxed arithmetic (v_rsq_f32 instead of
- * 1 / sqrtf, a host-computed 1 / (1 + lt) instead of the divide; within 1e-5 of the default on float32 duals, 1-2 % faster)
- * -- the default reproduces the rounding sequence of the reference's kernels (primal_dual_for_total_variation.cu:66-123,
- * rudin_osher_fatemi_total_variation.cu:51-61) bit for bit, for float32 and binary16 duals.  Anything else returns
- * TOMO_E_INVALID: the independent implementations and A/B builds used by tests/ and tools/ (bp 1/2, fp 1/2, pdtv 1/2/21,
- * roftv 1..4) and the measurement switches ("probe") exist only in libtomo_mi355x_dev.so (csrc/Makefile: `make dev`). */
+ * class.  The shipped library accepts exactly one other value: "pdtv" 22 = float32 duals with the rounding sequence of the
+ * reference's kernels reproduced bit for bit (primal_dual_for_total_variation.cu:66-123; FMA-corrected 1 / sqrtf and
+ * quotient), +16 % per launch.  The default runs float32 duals with relaxed arithmetic (v_rsq_f32 instead of 1 / sqrtf, a
+ * host-computed 1 / (1 + lt) instead of the divide: within 1e-5 of the reference, typically 3e-7); binary16 duals
+ * (half_precision) and ROF_TV reproduce the reference's roundings in every build (rudin_osher_fatemi_total_variation.cu:51-61).
+ * Anything else returns TOMO_E_INVALID: the independent implementations and A/B builds used by tests/ and tools/ (bp 1/2,
+ * fp 1/2, pdtv 1/2/3/21, roftv 1..4) and the measurement switches ("probe") exist only in libtomo_mi355x_dev.so
+ * (csrc/Makefile: `make dev`). */
 int tomo_set_variant(const char *kernel, int variant);
 
 /* In-library kernel timing for bench.py's roofline object: while enabled, every launch group of a kernel class

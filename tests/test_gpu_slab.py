@@ -21,7 +21,7 @@ def _copy_halos(states, b):
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("half", [False, True])
-@pytest.mark.parametrize("variant", [0, 3, "ranges", pytest.param(2, marks=pytest.mark.dev_variants),
+@pytest.mark.parametrize("variant", [0, 22, "ranges", pytest.param(2, marks=pytest.mark.dev_variants),
                                      pytest.param(1, marks=pytest.mark.dev_variants)])
 def test_pdtv_slabs_equal_whole_volume(world, half, variant):
     ranges = variant == "ranges"  # the overlapped schedule of pd_tv_slab: edge planes first, then the interior
@@ -145,7 +145,7 @@ def test_pdtv_thin_volumes_direct_abi():
     fewer iterations per launch; checked against the oracle's 3D kernel on the same un-squeezed shape."""
     from oracle import tomo_oracle as O
     from tomobar_amd import ops
-    for variant in (0,):   # the shipped kernels reproduce the oracle's roundings
+    for variant in (0, 22):   # as shipped (relaxed float32 arithmetic: tolerance) / the reference's roundings (bit for bit)
         ops.set_variant("pdtv", variant)
         for dz in (1, 2):
             rng = np.random.default_rng(dz)
@@ -159,5 +159,5 @@ def test_pdtv_thin_volumes_direct_abi():
             torch.cuda.synchronize()
             g = got.cpu().numpy()
             err = np.linalg.norm(g - want) / np.linalg.norm(want)
-            assert err < 1e-6 and np.array_equal(g, want), (variant, dz, err)
+            assert err < 1e-6 and (variant != 22 or np.array_equal(g, want)), (variant, dz, err)
     ops.set_variant("pdtv", 0)

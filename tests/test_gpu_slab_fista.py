@@ -45,7 +45,7 @@ def _worker(rank, world, port, case, backend="gloo"):
         from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
         from tomobar_amd.slab import SlabComm, slab_bounds
         from tomobar_amd import ops
-        ops.set_variant("pdtv", 0)   # the shipped TV kernels reproduce the oracle's roundings: the comparison below is bit for bit
+        ops.set_variant("pdtv", 22)  # the slab driver is under test: PD_TV with the reference's roundings keeps the comparison bit for bit
         ops.set_variant("roftv", 0)
         dev = torch.device("cuda", dev_index)
         nz, n, na, os_n = case["nz"], 40, 36, case["os"]

@@ -96,6 +96,8 @@ def test_ring_terms_hip_vs_oracle(oracle, case):
     else:
         d.update(ringGH_lambda=1e-4, ringGH_accelerate=4)
         ring = {"lambda": 1e-4, "accelerate": 4}
+    from tomobar_amd import ops
+    ops.set_variant("pdtv", 22)   # the ring terms are under test: PD_TV with the reference's roundings keeps the comparison bit for bit
     rt = RecToolsIRCuPy(n, 0, None if case == "gh_2d" else nz, 0.0, angles, n, 0, os_n if os_n > 1 else None)
     got = rt.FISTA(d, alg, reg)
     torch.cuda.synchronize()

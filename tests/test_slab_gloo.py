@@ -82,6 +82,50 @@ def test_slab_tv_matches_whole_volume(world, case):
     mp.start_processes(_worker, args=(world, _free_port(), case), nprocs=world, join=True, start_method="spawn")
 
 
+def _inflight_worker(rank, world, port):
+    """exchange_start / exchange_wait allow several exchanges in flight; each must own its staging buffers
+    from post to wait (a shared per-direction buffer would be overwritten by the second post).  Host tensors: packed by
+    slab.py itself, without the library."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tomobar_amd.slab import SlabComm
+        comm = SlabComm(rank, world)
+        lo, hi = rank > 0, rank < world - 1
+
+        def blocks(tag, sizes):
+            return [torch.full((k, 3, 5), float(100 * tag + 10 * rank + i)) for i, k in enumerate(sizes)]
+        sets = []
+        for tag, (up, down) in enumerate([((3, 3, 3, 3), (3, 2, 2, 2)), ((1, 4), (2,)), ((3, 3, 3, 3), (3, 2, 2, 2))]):
+            su = blocks(tag, up) if hi else []
+            sd = blocks(tag, down) if lo else []
+            ru = [torch.zeros((k, 3, 5)) for k in down] if hi else []
+            rd = [torch.zeros((k, 3, 5)) for k in up] if lo else []
+            sets.append((tag, sd, rd, su, ru, up, down))
+        handles = [comm.exchange_start(sd, rd, su, ru) for _, sd, rd, su, ru, _, _ in sets]   # three posts, nothing waited yet
+        for h in reversed(handles):                                                           # ... completed out of order
+            comm.exchange_wait(h)
+        for tag, sd, rd, su, ru, up, down in sets:
+            for i, t in enumerate(rd):
+                assert torch.all(t == float(100 * tag + 10 * (rank - 1) + i)), (rank, tag, i)
+            for i, t in enumerate(ru):
+                assert torch.all(t == float(100 * tag + 10 * (rank + 1) + i)), (rank, tag, i)
+        # the buffers went back to the pool and are reused by the next exchange (no growth beyond what was in flight)
+        pooled = len(comm._stage_free)
+        comm.exchange(sets[0][1], sets[0][2], sets[0][3], sets[0][4])
+        assert len(comm._stage_free) == pooled
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_several_exchanges_in_flight(world):
+    mp.start_processes(_inflight_worker, args=(world, _free_port()), nprocs=world, join=True, start_method="spawn")
+
+
 def _fista_worker(rank, world, port, case):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -80,6 +80,8 @@ def test_gpu_reconstruction_with_vertical_component(oracle, method, fid):
     sino = Pf.fp(np.random.default_rng(8).random((nz, n, n), dtype=np.float32)) / n + np.float32(0.01)
     Lc = oracle.power_method(P, np.random.default_rng(9).standard_normal((nz, n, n)).astype(np.float32))
     reg = {"method": "PD_TV", "regul_param": 0.002, "iterations": 6, "methodTV": 0, "PD_LipschitzConstant": 12.0}
+    from tomobar_amd import ops
+    ops.set_variant("pdtv", 22)   # the projector composition is under test: PD_TV with the reference's roundings keeps it bit for bit
     rt = RecToolsIRCuPy(n, 0, nz, cor, angles, n, 0, os_n)
     data = {"projection_data": sino, "data_axes_labels_order": ["detY", "angles", "detX"], "data_fidelity": fid}
     alg = {"iterations": 3, "lipschitz_const": Lc, "nonnegativity": True, "recon_mask_radius": None}

@@ -69,7 +69,18 @@ std::vector<float> make_filter(int n, float a, float mult)
 // The stream is part of the key: a plan owns ONE work area, so two streams must never execute the same plan concurrently
 // (successive calls on one stream are ordered by the stream itself).  At most FBP_MAX_PLANS pairs are kept per process,
 // least recently used first out (every distinct `rows` value is a plan pair with its own work area).
-struct fbp_plans { hipfftHandle fwd = 0, inv = 0; unsigned long long used = 0; };
+// `done` is recorded after every execution: eviction / release wait on THAT event before the work areas are freed, never
+// on the stream handle -- the caller may have destroyed the stream since (CuPy / user-created streams), and an event
+// owned by the library stays valid whatever happened to the stream it was recorded on.
+struct fbp_plans { hipfftHandle fwd = 0, inv = 0; hipEvent_t done = nullptr; unsigned long long used = 0; };
+
+void fbp_destroy(fbp_plans &p)
+{
+    if (p.done) { (void)hipEventSynchronize(p.done); (void)hipEventDestroy(p.done); }
+    if (p.fwd) (void)hipfftDestroy(p.fwd);
+    if (p.inv) (void)hipfftDestroy(p.inv);
+    p = fbp_plans{};
+}
 std::mutex g_fbp_mu;
 constexpr size_t FBP_MAX_PLANS = 8;
 unsigned long long g_fbp_tick = 0;
@@ -85,11 +96,9 @@ int fbp_get_plans(int device, hipStream_t st, int nu, size_t rows, fbp_plans &ou
         auto victim = g_fbp_plans.begin();
         for (auto jt = g_fbp_plans.begin(); jt != g_fbp_plans.end(); ++jt)
             if (jt->second.used < victim->second.used) victim = jt;
-        // the victim's last execution may still be running on its stream: hipfftDestroy frees the work area
+        // the victim's last execution may still be running: wait for its event, then free the work areas
         tomo_device_guard guard(std::get<0>(victim->first));
-        (void)hipStreamSynchronize(std::get<1>(victim->first));
-        (void)hipfftDestroy(victim->second.fwd);
-        (void)hipfftDestroy(victim->second.inv);
+        fbp_destroy(victim->second);
         g_fbp_plans.erase(victim);
     }
     const int nh = nu / 2 + 1;
@@ -99,9 +108,9 @@ int fbp_get_plans(int device, hipStream_t st, int nu, size_t rows, fbp_plans &ou
     if (r == HIPFFT_SUCCESS) r = hipfftPlanMany(&p.inv, 1, n, nullptr, 1, nh, nullptr, 1, nu, HIPFFT_C2R, (int)rows);
     if (r == HIPFFT_SUCCESS) r = hipfftSetStream(p.fwd, st);
     if (r == HIPFFT_SUCCESS) r = hipfftSetStream(p.inv, st);
+    if (r == HIPFFT_SUCCESS && hipEventCreateWithFlags(&p.done, hipEventDisableTiming) != hipSuccess) { p.done = nullptr; r = HIPFFT_INTERNAL_ERROR; }
     if (r != HIPFFT_SUCCESS) {  // nothing half-built is kept or leaked
-        if (p.fwd) (void)hipfftDestroy(p.fwd);
-        if (p.inv) (void)hipfftDestroy(p.inv);
+        fbp_destroy(p);
         return tomo_fail(TOMO_E_RUNTIME, "hipfftPlanMany failed: hipfft status %d", (int)r);
     }
     p.used = ++g_fbp_tick;
@@ -136,8 +145,7 @@ void tomo_fbp_cache_release(int device)
     tomo_device_guard guard(device);
     for (auto it = g_fbp_plans.begin(); it != g_fbp_plans.end();) {
         if (std::get<0>(it->first) == device) {
-            (void)hipfftDestroy(it->second.fwd);
-            (void)hipfftDestroy(it->second.inv);
+            fbp_destroy(it->second);   // waits for the plan's last execution (its event), whatever became of the stream
             it = g_fbp_plans.erase(it);
         } else ++it;
     }
@@ -177,5 +185,6 @@ extern "C" int tomo_fbp_filter(int device, float *data_dev, size_t rows, int nu,
     apply_filter_kernel<<<(unsigned)grid, 256, 0, st>>>(spec, filt, rows, nh);
     TOMO_LAUNCH_CHECK();
     TOMO_FFT(hipfftExecC2R(p.inv, (hipfftComplex *)spec, data_dev));
+    TOMO_HIP(hipEventRecord(p.done, st));
     return TOMO_OK;  // asynchronous on `st`: no host synchronisation
 }

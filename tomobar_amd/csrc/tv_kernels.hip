@@ -274,10 +274,14 @@ __device__ __forceinline__ float mk_sqrt(float x)
     h = fmaf(h, e, h);
     return fmaf(fmaf(-q, q, x), h, q);
 }
+// 1.0f / q correctly rounded: v_rcp_f32 (1 ulp) + ONE Newton step.  On gfx950 that equals the IEEE quotient for every one of
+// the 1 677 721 601 floats in [2^-100, 2^100] (tools/probes/recip_allones_probe.hip, profiles/r4d_recip_allones_probe.txt;
+// round 3 used two steps).  The textbook counter-example q = 0x1.fffffep+k -- where a v_rcp that returned the 1-ulp-low
+// 2^-(k+1) would leave the Newton update on an exact tie -- does not occur: this hardware's v_rcp_f32 returns RN(1/q)
+// there in every binade.
 __device__ __forceinline__ float mk_recip(float q)
 {
-    float y = __builtin_amdgcn_rcpf(q);
-    y = fmaf(fmaf(-q, y, 1.0f), y, y);
+    const float y = __builtin_amdgcn_rcpf(q);
     return fmaf(fmaf(-q, y, 1.0f), y, y);
 }
 
@@ -357,11 +361,7 @@ __device__ __forceinline__ void pd_dual_block(float (&p)[NB][3], const float (&g
 #pragma unroll
         for (int k = 0; k < NB; ++k) e[k] = fmaf(-q[k], h[k], 1.0f);
 #pragma unroll
-        for (int k = 0; k < NB; ++k) h[k] = fmaf(e[k], h[k], h[k]);
-#pragma unroll
-        for (int k = 0; k < NB; ++k) e[k] = fmaf(-q[k], h[k], 1.0f);
-#pragma unroll
-        for (int k = 0; k < NB; ++k) h[k] = fmaf(e[k], h[k], h[k]);   // = 1.0f / sqrtf(nrm)
+        for (int k = 0; k < NB; ++k) h[k] = fmaf(e[k], h[k], h[k]);   // = 1.0f / sqrtf(nrm) (one Newton step: see mk_recip)
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const float rr = nrm[k] > 1.0f ? h[k] : 1.0f;
@@ -422,44 +422,55 @@ __device__ __forceinline__ void pd_primal_block(float (&out)[NB], const float (&
 #include "pd_rows2d.inl"
 
 // Several iterations in one pass through HBM (3D).  `k` = iterations of this launch (2 or 3).
-//   variant 0 (shipped default): the reference's roundings through FMA correction steps (FAST = 2) for float32 and
-//              binary16 duals: k = 3 -> pd_zmarch_xk<K=3, 8 rows, 2x2 waves, LDS lag>, k = 2 -> pd_zmarch_x2<2x2 waves>.
-//              Bit-identical to the oracle.  (Rounds 2-3 shipped relaxed arithmetic for float32 duals; measured on the
-//              final round-3 kernels the exact build costs 1-2 %: 3.94 vs 4.01 ms per 1024^3 iteration in a
-//              10-iteration call, profiles/r4a_kernel_bench_1024.txt -- parity is worth more than that.)
-//   variant 3 (shipped, opt-in): relaxed arithmetic for both dual types on the same tilings -- v_rsq_f32 instead of
-//              1 / sqrtf, a host-computed 1 / (1 + lt) instead of the divide; <= 1e-5 from the default on float32 duals.
-//   variant 2 (dev): the compiler's IEEE sqrt / divide sequences, two iterations per launch (pd_zmarch_x2, 2x2 waves);
-//   variant 21 (dev): the same on the K = 3 tiling.  Both bit-identical to the oracle: the independent exactness check.
+//   variant 0 (shipped default): float32 duals with relaxed arithmetic (FAST = 1: v_rsq_f32 instead of 1 / sqrtf, a
+//              host-computed 1 / (1 + lt) instead of the divide; <= 1e-5 from the reference, typically 3e-7), binary16 duals
+//              with the reference's roundings (FAST = 2; one flipped binary16 rounding is 5e-4 of a dual value, relaxed
+//              arithmetic cannot hold the 1e-5 parity bar there).  k = 3 -> pd_zmarch_xk<K=3, 8 rows, 2x2 waves, LDS lag>,
+//              k = 2 -> pd_zmarch_x2.
+//   variant 22 (shipped, opt-in): the reference's roundings through FMA correction steps (FAST = 2) for float32 duals as
+//              well, same tilings: bit-identical to the oracle.  Round 4, same box, 30-iteration prox at 1024^3: 10.65 ms per
+//              three-iteration launch against 9.17 relaxed (+16 %; 0.636 vs 0.717 outer iterations/s on the bench,
+//              profiles/r4d_bench_exact_vs_relaxed.txt) -- the ~390 extra VALU instructions per plane of the correction
+//              chains (two quarter-rate transcendentals and 14 dependent FMAs per dual row) on a kernel that is bound by
+//              instruction issue.  That is why it is not the default.
+//   dev flavour: 3 = relaxed arithmetic for both dual types; 2 = the compiler's IEEE sqrt / divide sequences, two iterations
+//              per launch (pd_zmarch_x2, 2x2 waves); 21 = the same on the K = 3 tiling.  2 and 21 are bit-identical to the
+//              oracle: the independent exactness check of the FMA-corrected build.
 static int pd_iters_per_launch(int variant)
 {
     if (variant == 1) return 1;
     return variant == 2 ? 2 : 3;
 }
 
+// arithmetic level of a shipped / relaxed / exact variant for dual type T (the dev builds 2 / 21 use FAST = 0 explicitly)
+template <typename T>
+constexpr bool pd_default_is_exact() { return sizeof(T) == 2; }
+
 // three iterations per launch: 8 rows per lane, 10 of the 90 hand-over slots in registers (80 KB of LDS per workgroup = two
 // workgroups per CU)
 template <typename T, bool NN, bool AN>
 int pd_xk3_launch(const PdArgs &a, int variant, hipStream_t st)
 {
-    if (variant == 3) return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 2, 2, true, 10>(a, st);
 #if TOMO_DEV
+    if (variant == 3) return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 2, 2, true, 10>(a, st);
     if (variant == 21) {
         if constexpr (sizeof(T) == 4) return pd_zmarch_xk_launch<T, NN, AN, 0, 3, 8, 2, 2, true, 10>(a, st);
         else return pd_zmarch_xk_launch<T, NN, AN, 0, 3, 4, 2, 2, true>(a, st);  // 4 rows per lane: the IEEE expansions need the registers
     }
 #endif
-    return pd_zmarch_xk_launch<T, NN, AN, 2, 3, 8, 2, 2, true, 10>(a, st);
+    if (variant == 22 || pd_default_is_exact<T>()) return pd_zmarch_xk_launch<T, NN, AN, 2, 3, 8, 2, 2, true, 10>(a, st);
+    return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 2, 2, true, 10>(a, st);
 }
 
 template <typename T, bool NN, bool AN>
 int pd_x2_launch(const PdArgs &a, int variant, hipStream_t st)
 {
-    if (variant == 3) return pd_zmarch_x2_launch<T, NN, AN, 1, 4, 2, 4>(a, st);
 #if TOMO_DEV
+    if (variant == 3) return pd_zmarch_x2_launch<T, NN, AN, 1, 4, 2, 4>(a, st);
     if (variant == 2 || variant == 21) return pd_zmarch_x2_launch<T, NN, AN, 0, 4, 2, 2>(a, st);
 #endif
-    return pd_zmarch_x2_launch<T, NN, AN, 2, 4, 2, 2>(a, st);
+    if (variant == 22 || pd_default_is_exact<T>()) return pd_zmarch_x2_launch<T, NN, AN, 2, 4, 2, 2>(a, st);
+    return pd_zmarch_x2_launch<T, NN, AN, 1, 4, 2, 4>(a, st);
 }
 
 template <typename T>
@@ -489,10 +500,11 @@ int pd_rows2d_k(const PdArgs &a, int k, hipStream_t st)
 template <typename T>
 int pd_2d_launch(const PdArgs &a, int k, int methodTV, int nonneg, int variant, hipStream_t st)
 {
+    const bool exact = variant == 22 || pd_default_is_exact<T>();
 #if TOMO_DEV
-#define PD_2D_F(NN, AN) (variant == 3 ? pd_rows2d_k<T, NN, AN, 1>(a, k, st) : (variant == 2 || variant == 21) ? pd_rows2d_k<T, NN, AN, 0>(a, k, st) : pd_rows2d_k<T, NN, AN, 2>(a, k, st))
+#define PD_2D_F(NN, AN) ((variant == 2 || variant == 21) ? pd_rows2d_k<T, NN, AN, 0>(a, k, st) : (variant == 3 || !exact) ? pd_rows2d_k<T, NN, AN, 1>(a, k, st) : pd_rows2d_k<T, NN, AN, 2>(a, k, st))
 #else
-#define PD_2D_F(NN, AN) (variant == 3 ? pd_rows2d_k<T, NN, AN, 1>(a, k, st) : pd_rows2d_k<T, NN, AN, 2>(a, k, st))
+#define PD_2D_F(NN, AN) (exact ? pd_rows2d_k<T, NN, AN, 2>(a, k, st) : pd_rows2d_k<T, NN, AN, 1>(a, k, st))
 #endif
     int rc;
     if (!nonneg && !methodTV) rc = PD_2D_F(false, false);
@@ -525,9 +537,11 @@ int pd_launch(const PdArgs &a0, int variant, hipStream_t st)
     }
     if (variant == 2 || variant == 21) rc = pd_zmarch2_launch<T, ND, NONNEG, ANISO, 0, 8, true, 4, 2>(a, st);
     else
-#endif
     if (variant == 3) rc = pd_zmarch2_launch<T, ND, NONNEG, ANISO, 1, 8, true, 4, 2>(a, st);
-    else rc = pd_zmarch2_launch<T, ND, NONNEG, ANISO, 2, 8, true, 4, 2>(a, st);
+    else
+#endif
+    if (variant == 22 || pd_default_is_exact<T>()) rc = pd_zmarch2_launch<T, ND, NONNEG, ANISO, 2, 8, true, 4, 2>(a, st);
+    else rc = pd_zmarch2_launch<T, ND, NONNEG, ANISO, 1, 8, true, 4, 2>(a, st);
     if (rc != TOMO_OK) return rc;
     TOMO_LAUNCH_CHECK();
     return TOMO_OK;

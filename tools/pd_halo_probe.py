@@ -13,7 +13,7 @@ from tomobar_amd import ops
 from tomobar_amd.regularisersCuPy import PD_TV_cupy
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 IT = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-ops.set_variant("pdtv", int(sys.argv[3]) if len(sys.argv) > 3 else 0)   # 0 = shipped exact roundings, 3 = relaxed
+ops.set_variant("pdtv", int(sys.argv[3]) if len(sys.argv) > 3 else 0)   # 0 = shipped default (relaxed float32), 22 = the reference's roundings
 vol = torch.rand((N, N, N), device="cuda")
 out = torch.empty_like(vol)
 res = {}
