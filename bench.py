@@ -105,6 +105,8 @@ def parse():
     p.add_argument("--ring", type=float, default=None, help="Group-Huber ring term: ringGH_lambda (BASELINE configs[4])")
     p.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    p.add_argument("--no-pmc", action="store_true",
+                   help="skip the live rocprofv3 --pmc passes that measure roofline.traffic (N = 1 only; ~1 minute)")
     p.add_argument("--cpu-slices", type=int, default=8)
     p.add_argument("--exact-tv", action="store_true",
                    help="PD_TV float32 duals with the reference's rounding sequence (tomo_set_variant('pdtv', 22): bit-identical "
@@ -256,6 +258,59 @@ def cpu_baseline(args, sino_dev, lc):
     return {"value": its_full, "unit": "iterations/s", "cores": cores, "kind": "port",
             "sample": f"oracle/tomo_oracle.c (OpenMP, {cores} threads): 1 outer {args.method} iteration on {nzs} of the "
                       f"{nz} slices of the GPU leg's own sinogram ({dt:.1f} s), scaled by {nzs}/{nz}"}
+
+
+def live_traffic(dom, args, n, nz, sub):
+    """HBM traffic per launch of the dominant kernel, measured NOW on this box: two separate `rocprofv3 --pmc` passes
+    (FETCH_SIZE, then WRITE_SIZE; kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over
+    tools/pmc_probe.py, which launches that kernel on the bench's own shape in a child process.  FETCH_SIZE is doubled (the
+    guide's gfx950 correction: 128-B requests are tallied as 64 B; calibrated on a dword stream in profiles/r1_pdtv_pmc.txt),
+    values are KiB.  Returns (bytes per launch, description) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    what = {"pdtv": ("pdtv22" if getattr(args, "exact_tv", False) else "pdtv0") + ("h" if args.half else ""),
+            "roftv": "roftv", "bp": "bp0", "fp": "fp"}[dom]
+    key = {"pdtv": ["xk_kernel"], "roftv": ["rof_"], "bp": ["bp_brick"], "fp": ["fp_tiled", "transpose"]}[dom]
+    tmp = tempfile.mkdtemp(prefix="tomo_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", PMC_PD_ITERS="9")
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py"), what, str(n), str(nz), str(sub)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            rows = [row for row in csv.DictReader(open(files[0])) if row.get("Counter_Name") == counter]
+            got[counter] = [[float(row["Counter_Value"]) for row in rows if k in row["Kernel_Name"]] for k in key]
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+        return None, f"counter pass failed: {e!r}"[:160]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    kib = lambda f, w: (2.0 * f + w) * 1024.0  # noqa: E731
+    try:
+        if dom == "pdtv":      # a 9-iteration prox = first (no dual reads) + middle + last (no dual stores) launch
+            f, w = got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
+            tr = [kib(a, b) for a, b in zip(f, w)]
+            assert len(tr) == 3
+            plan_launches = max(1, -(-args.inner // 3))
+            mean = (tr[0] + tr[2] + (plan_launches - 2) * tr[1]) / plan_launches if plan_launches >= 2 else tr[1]
+            return mean, (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py {what} {n} {nz} on this box; "
+                          f"first / middle / last launch {tr[0]:.4g} / {tr[1]:.4g} / {tr[2]:.4g} B, mean of the {plan_launches} launches of a prox")
+        if dom == "fp":        # one call = two stepping-axis launches + the in-plane transpose; the probe makes two calls
+            fs = sum(sum(v) for v in got["FETCH_SIZE"]) / 2.0
+            ws = sum(sum(v) for v in got["WRITE_SIZE"]) / 2.0
+            return kib(fs, ws), f"live: rocprofv3 --pmc passes over tools/pmc_probe.py fp {n} {nz} {sub}; per forward projection (2 launches + transpose)"
+        f, w = got["FETCH_SIZE"][0][-1], got["WRITE_SIZE"][0][-1]   # steady-state launch: the last one
+        return kib(f, w), f"live: rocprofv3 --pmc passes over tools/pmc_probe.py {what} {n} {nz} {sub}; last launch"
+    except (AssertionError, IndexError) as e:
+        return None, f"unexpected counter rows: {e!r}"
 
 
 def footprint_bytes(args, nz):
@@ -426,6 +481,15 @@ def measure(args, env):
                     traffic = ent["traffic_bytes"]
         except (OSError, ValueError):
             pass
+        # ... and, on one GPU, measured live by this very run (unless --no-pmc): the committed figure stays in the line as
+        # `traffic_committed` for comparison
+        traffic_committed = traffic
+        if world == 1 and not getattr(args, "no_pmc", False):
+            torch.cuda.empty_cache()
+            live, how = live_traffic(dom, args, n, nz, sub)
+            if live is not None:
+                traffic = live
+            traffic_src = dict(traffic_src or {}, live=how)
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": kernels[dom]["avg_ms"], "launches": kernels[dom]["launches"],
@@ -435,6 +499,8 @@ def measure(args, env):
         if dom == "pdtv":
             roof["iterations_per_launch"] = kernels[dom]["iterations_per_launch"]
             roof["alg_GBps_per_iteration_equiv"] = kernels[dom]["alg_GBps_per_iteration_equiv"]
+        if traffic_committed is not None:
+            roof["traffic_committed"] = traffic_committed
         if traffic is not None:
             roof["traffic_GBps"] = traffic / kernels[dom]["avg_ms"] / 1e6
             roof["frac_traffic"] = roof["traffic_GBps"] / HBM_PEAK_GBS

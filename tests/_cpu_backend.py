@@ -111,6 +111,8 @@ def make_ops():
     m = types.ModuleType("cpu_ops")
     m.to_device = lambda x, device_index=0: x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
     m.contiguous = lambda t: t.contiguous()
+    from tomobar_amd import ops as real_ops   # array-library plumbing is pure Python: the product's own functions
+    m.like, m.is_cupy, m.base_ptr = real_ops.like, real_ops.is_cupy, real_ops.base_ptr
     m.fill = lambda x, v: x.fill_(float(v))
     m.momentum = lambda x, xo, xt, beta: _put(xt, _np(x) + np.float32(beta) * (_np(x) - _np(xo)))
     m.admm_dual = lambda u, z, x: _put(u, _np(u) + (_np(z) - _np(x)))
