@@ -110,7 +110,7 @@ def parse():
     p.add_argument("--cpu-slices", type=int, default=8)
     p.add_argument("--exact-tv", action="store_true",
                    help="PD_TV float32 duals with the reference's rounding sequence (tomo_set_variant('pdtv', 22): bit-identical "
-                        "to the oracle, +16 %% per launch; the default is within 1e-5); the workload string says so")
+                        "to the oracle, +5 ... +16 %% per launch; the default is within 1e-5); the workload string says so")
     p.add_argument("--no-north-star", action="store_true",
                    help="N > 1 only: skip the extra `north_star` block (strong scaling of configs[4] when it fits)")
     if len(sys.argv) == 1 and "TOMO_BENCH_ARGV" in os.environ and "RANK" in os.environ:  # rank started by self_launch()

@@ -321,7 +321,7 @@ int tomo_fourier_inv(int device, const float *data_dev, float *out_dev, int nz, 
 /* kernel-variant selector (per calling host thread): name in {"bp","fp","pdtv","roftv"}; variant 0 = the default of every
  * class.  The shipped library accepts exactly one other value: "pdtv" 22 = float32 duals with the rounding sequence of the
  * reference's kernels reproduced bit for bit (primal_dual_for_total_variation.cu:66-123; FMA-corrected 1 / sqrtf and
- * quotient), +16 % per launch.  The default runs float32 duals with relaxed arithmetic (v_rsq_f32 instead of 1 / sqrtf, a
+ * quotient), +5 ... +16 % per launch depending on the box.  The default runs float32 duals with relaxed arithmetic (v_rsq_f32 instead of 1 / sqrtf, a
  * host-computed 1 / (1 + lt) instead of the divide: within 1e-5 of the reference, typically 3e-7); binary16 duals
  * (half_precision) and ROF_TV reproduce the reference's roundings in every build (rudin_osher_fatemi_total_variation.cu:51-61).
  * Anything else returns TOMO_E_INVALID: the independent implementations and A/B builds used by tests/ and tools/ (bp 1/2,

@@ -39,7 +39,7 @@ def _library_flavour(request):
 
 # ---- PD_TV arithmetic.  The shipped default runs float32 duals with relaxed arithmetic (v_rsq_f32, hoisted reciprocal: <= 1e-5
 # from the reference; binary16 duals always reproduce the reference's roundings); tomo_set_variant("pdtv", 22) selects the
-# reference's roundings for float32 duals too (bit-identical, +16 % per launch).  Every GPU test that touches PD_TV takes the
+# reference's roundings for float32 duals too (bit-identical, +5 ... +16 % per launch).  Every GPU test that touches PD_TV takes the
 # `pd_arith` fixture and so runs TWICE against the shipped library: "default" = the kernel bench.py times, held to the
 # north-star tolerance and logged with bit-level statistics; "exact" = variant 22, held to bit equality.
 PD_BITSTATS = []

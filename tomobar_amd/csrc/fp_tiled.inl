@@ -88,7 +88,11 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
     // 2.05 -> 1.69 LDS cycles per group access.  The staging keeps its lane-linear columns (tid); only the ray a lane
     // owns -- and hence the 4-byte column it stores in the sinogram row -- moves inside the wave's 64-pixel segment.
     const int lane = tid & 63;
+#ifdef TOMO_FP_NO_LANE_PERM   // A/B builds only (tools/run_ab.sh): pixel = lane, the round-3 mapping
+    const int lane_pix = lane;
+#else
     const int lane_pix = fp_lane_pixel(lane);
+#endif
     const int iu = u0 + (tid - lane) + lane_pix;
     const int n = a.n;
     const int ng = min(FP_A, a.n_class - g * FP_A);   // angles in this group (uniform)

@@ -428,11 +428,11 @@ __device__ __forceinline__ void pd_primal_block(float (&out)[NB], const float (&
 //              arithmetic cannot hold the 1e-5 parity bar there).  k = 3 -> pd_zmarch_xk<K=3, 8 rows, 2x2 waves, LDS lag>,
 //              k = 2 -> pd_zmarch_x2.
 //   variant 22 (shipped, opt-in): the reference's roundings through FMA correction steps (FAST = 2) for float32 duals as
-//              well, same tilings: bit-identical to the oracle.  Round 4, same box, 30-iteration prox at 1024^3: 10.65 ms per
-//              three-iteration launch against 9.17 relaxed (+16 %; 0.636 vs 0.717 outer iterations/s on the bench,
-//              profiles/r4d_bench_exact_vs_relaxed.txt) -- the ~390 extra VALU instructions per plane of the correction
-//              chains (two quarter-rate transcendentals and 14 dependent FMAs per dual row) on a kernel that is bound by
-//              instruction issue.  That is why it is not the default.
+//              well, same tilings: bit-identical to the oracle.  Round 4, same-box pairs, 30-iteration prox at 1024^3: 10.5-10.7 ms
+//              per three-iteration launch against 9.2 (one box, +16 %; 0.636 vs 0.717 outer iterations/s on the bench,
+//              profiles/r4d_bench_exact_vs_relaxed.txt) or 10.05 (another box, +4.6 %; 0.645 vs 0.668) relaxed -- the ~390
+//              extra VALU instructions per plane of the correction chains (two quarter-rate transcendentals and 13
+//              dependent FMAs per dual row) on a kernel that is bound by instruction issue.  That is why it is not the default.
 //   dev flavour: 3 = relaxed arithmetic for both dual types; 2 = the compiler's IEEE sqrt / divide sequences, two iterations
 //              per launch (pd_zmarch_x2, 2x2 waves); 21 = the same on the K = 3 tiling.  2 and 21 are bit-identical to the
 //              oracle: the independent exactness check of the FMA-corrected build.

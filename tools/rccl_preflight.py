@@ -56,6 +56,12 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)]
         sys.exit(subprocess.call(cmd, env=env))
 
+    # everything a library prints on stdout during the run (gloo announces its connections there) goes to stderr, so that
+    # the ONE JSON line of rank 0 is all stdout carries
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from tomobar_amd.regularisersCuPy import PD_TV_cupy
@@ -141,7 +147,7 @@ def main():
     if rank == 0:
         print(json.dumps({"tool": "rccl_preflight", "world": world, "gpus_visible": ndev, "backend": backend,
                           "note": note, "gloo_init_s": t_gloo, "rccl_group_s": t_nccl, "plane": [n, n],
-                          "kernel": f"PD_TV x3 on {args.nz} x {n}^2", "ranks": allr}), flush=True)
+                          "kernel": f"PD_TV x3 on {args.nz} x {n}^2", "ranks": allr}), file=json_out, flush=True)
     dist.destroy_process_group()
 
 
