@@ -272,6 +272,8 @@ def live_traffic(dom, args, n, nz, sub):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this process already runs under a profiler: no nested counter passes"
     what = {"pdtv": ("pdtv22" if getattr(args, "exact_tv", False) else "pdtv0") + ("h" if args.half else ""),
             "roftv": "roftv", "bp": "bp0", "fp": "fp"}[dom]
     key = {"pdtv": ["xk_kernel"], "roftv": ["rof_"], "bp": ["bp_brick"], "fp": ["fp_tiled", "transpose"]}[dom]

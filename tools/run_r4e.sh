@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 T=${1:-r4e}; O=gpurun_out/$T; mkdir -p $O
 timeout 2700 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu > $O/bench_prof_line.json 2> $O/bench_prof.err
+rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu --no-pmc > $O/bench_prof_line.json 2> $O/bench_prof.err
 DB=$(find $O/prof -name "*.db" | head -1)
 python tools/rocpd_summary.py "$DB" $O/bench_kernel_stats.txt | head -8
 find $O/prof -type f -size +1M -delete
