@@ -456,6 +456,19 @@ def test_tv_large_odd_shapes(oracle, ops, seed, pd_variants):
     assert np.array_equal(got, want_rof), ("rof", shape, iters, half, np.abs(got - want_rof).max())
 
 
+@pytest.mark.parametrize("shape,iters", [((1023, 2049), 7), ((2500, 777), 30), ((64, 5000), 4), ((3000, 61), 5)])
+def test_pdtv_2d_large_images(oracle, ops, shape, iters, pd_arith):
+    """The fused 2D kernel (pd_rows2d.inl: three iterations per launch, remainders of two / one) on images with hundreds of
+    tiles, ragged edges in both directions, very wide / very tall aspect ratios; float32 and binary16 duals, both TV norms."""
+    from tomobar_amd.regularisersCuPy import PD_TV_cupy
+    rng = np.random.default_rng(31)
+    x = (rng.random(shape) * 0.4 + (np.indices(shape)[-1] > shape[-1] // 3) + 0.5 * (np.indices(shape)[0] % 37 > 18) - 0.3).astype(np.float32)
+    for half, mtv, nn in ((False, 0, 1), (True, 1, 0)):
+        want = oracle.pd_tv(x, 0.03, iters, mtv, nn, 12.0, half)
+        got = host(PD_TV_cupy(dev(x), 0.03, iters, mtv, nn, 12.0, 0, half))
+        pd_arith.check(got, want, half=half, what=f"2D {shape} x{iters}")
+
+
 @pytest.mark.parametrize("flavour", ["shipped", pytest.param("dev", marks=DEV)])
 @pytest.mark.parametrize("seed", range(16))
 def test_tv_random_shapes(oracle, ops, seed, flavour):
