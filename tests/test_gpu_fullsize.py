@@ -162,6 +162,9 @@ def test_config3_shape_projector_pair_against_oracle(oracle):
     got = H.forward(torch.from_numpy(base_v).cuda() * sc, None)
     want = torch.from_numpy(P1.fp(base_v, None)).cuda() * sc
     assert torch.equal(got, want), float((got - want).abs().max())
+    # 1500 angles, no subsets: neighbours in the slope order are 0.12 degrees apart -> the dense-angle form (round 4)
+    print("configs[3] forward-projection path:", H.kernel_path("fp"))
+    assert "dense(256 pixels x 16 angles" in H.kernel_path("fp"), H.kernel_path("fp")
     del got, want
     base_s = rng.standard_normal((1, na, n)).astype(np.float32)
     got = H.backward(torch.from_numpy(base_s).cuda() * sc, None)

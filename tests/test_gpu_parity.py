@@ -114,6 +114,28 @@ def test_forward_projection_oblique_windows(oracle, ops, n, na, os_n, variant):
         assert np.array_equal(got, P.fp(vol, s)), (n, na, s)
 
 
+@pytest.mark.dev_variants
+@pytest.mark.parametrize("g", [(6, 300, 300, 400, 0.0, 1), (5, 520, 700, 300, 1.5, 1), (9, 200, 333, 512, "vec", 2),
+                               (4, 1100, 1100, 360, -2.0, 1)])
+def test_forward_projection_dense_angle_form(oracle, ops, g):
+    """The dense-angle form of the forward projector (256 pixels x 16 angles per workgroup, round 4), forced wherever it is
+    applicable (fp variant 3, dev flavour): bit for bit against the oracle, plain and with the residual epilogue."""
+    P, H = make_pair(oracle, g)
+    ops.set_variant("fp", 3)
+    rng = np.random.default_rng(12)
+    vol = rng.standard_normal((P.nz, P.n, P.n)).astype(np.float32)
+    b = rng.random((P.nz, P.na, P.nu)).astype(np.float32)
+    for s in ([None] if P.os_number == 1 else list(range(P.os_number))):
+        want = P.fp(vol, s)
+        got = host(H.forward(dev(vol), s))
+        assert "dense(256 pixels x 16 angles" in H.kernel_path("fp"), H.kernel_path("fp")
+        assert np.array_equal(got, want), (g, s, np.abs(got - want).max())
+        res = torch.empty(H.sino_shape(s), dtype=torch.float32, device="cuda")
+        H.residual(dev(vol), dev(b), None, "LS", s, res)
+        idx = P.subsets[s] if s is not None else slice(None)
+        assert np.array_equal(host(res), (want - b[:, idx]).astype(np.float32)), (g, s)
+
+
 @pytest.mark.parametrize("bp_variants", [(0,), pytest.param((1, 2), marks=DEV)])
 def test_lerp8_mode_and_reference_literals(oracle, ops, bp_variants):
     """tests/test_RecToolsDIRCuPy.py:671-694 of the reference: ones(128,160,160) -> min 67.27458 max 225.27428."""

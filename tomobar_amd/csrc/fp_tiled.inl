@@ -53,7 +53,9 @@ __device__ __forceinline__ int fp_lane_pixel(int lane)
     return (lane & 32) | (odd << 4) | ((q >> 1) << 2) | (lane & 3);
 }
 
-template <bool LERP8, bool RESID, int PASSES, int M, bool DB, int BT>
+// A = angles per workgroup: 8 (FP_A) everywhere except the dense-angle form of round 4 (256 pixels x 16 angles: half the
+// stagings per sample for angle sets whose neighbours in the slope order are a fraction of a degree apart, BASELINE configs[3])
+template <bool LERP8, bool RESID, int PASSES, int M, bool DB, int BT, int A = 8>
 __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
 {
     constexpr int KC = M / PASSES;
@@ -95,13 +97,13 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
 #endif
     const int iu = u0 + (tid - lane) + lane_pix;
     const int n = a.n;
-    const int ng = min(FP_A, a.n_class - g * FP_A);   // angles in this group (uniform)
-    const int *ord = a.order + g * FP_A;
+    const int ng = min(A, a.n_class - g * A);   // angles in this group (uniform)
+    const int *ord = a.order + g * A;
 
     const float half_n = 0.5f * (float)n - 0.5f, half_u = 0.5f * (float)a.nu - 0.5f, nf = (float)n;
-    float offs[FP_A], slope[FP_A], acc[FP_A][4];
+    float offs[A], slope[A], acc[A][4];
 #pragma unroll
-    for (int i = 0; i < FP_A; ++i) {
+    for (int i = 0; i < A; ++i) {
         const tomo_angle_t t = a.tab[ord[i < ng ? i : 0]];
         const float s = ((float)iu - half_u) + t.cor;
         offs[i] = fmaf(s, t.inv, half_n);
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
             asm("" : "+s"(rb));  // opaque: otherwise the *16 is factored back out and costs a second VALU op per tap
             const char *trow = reinterpret_cast<const char *>(tile);
 #pragma unroll
-            for (int i = 0; i < FP_A; ++i) {  // slots >= ng repeat angle 0 (never stored)
+            for (int i = 0; i < A; ++i) {  // slots >= ng repeat angle 0 (never stored)
                 const float f = fmaf(kw, slope[i], offs[i]);
                 const float fl = floorf(f);
                 const float w = lerp_w<LERP8>(f, fl), omw = 1.0f - w;
@@ -226,31 +228,35 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
         }
     }
     if (iu >= a.nu) return;
+    // (guards instead of `break`s: with 16 angles the unroller gives up on an early-exit loop and the accumulator array,
+    // indexed by a run-time `i`, lands in scratch memory)
 #pragma unroll
-    for (int i = 0; i < FP_A; ++i) {
-        if (i >= ng) break;
-        const int k_a = ord[i];
-        const tomo_angle_t t = a.tab[k_a];
+    for (int i = 0; i < A; ++i) {
+        if (i < ng) {
+            const int k_a = ord[i];
+            const tomo_angle_t t = a.tab[k_a];
 #pragma unroll
-        for (int zz = 0; zz < 4; ++zz) {
-            const int z = z0 + zz;
-            if (z >= a.nz) break;
-            float val = acc[i][zz] * t.scale;
-            if (RESID) {
-                const size_t gi = ((size_t)z * a.na + k_a) * a.nu + iu;
-                const size_t fi = ((size_t)z * a.na_full + t.src) * a.nu + iu;
-                const float bv = a.b[(a.gathered & TOMO_GATHERED_B) ? gi : fi];
-                if (a.fidelity == TOMO_FID_KL || a.fidelity == TOMO_FID_RATIO) {
-                    const float ax = val < 1e-8f ? 1e-8f : val;
-                    const float qv = bv / ax;
-                    val = (a.fidelity == TOMO_FID_KL) ? 1.0f - qv : qv;
-                } else {
-                    val = val - bv;
-                    if (a.ring) val = val + a.ring_scale * a.ring[(size_t)z * a.nu + iu];
-                    if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
+            for (int zz = 0; zz < 4; ++zz) {
+                const int z = z0 + zz;
+                if (z < a.nz) {
+                    float val = acc[i][zz] * t.scale;
+                    if (RESID) {
+                        const size_t gi = ((size_t)z * a.na + k_a) * a.nu + iu;
+                        const size_t fi = ((size_t)z * a.na_full + t.src) * a.nu + iu;
+                        const float bv = a.b[(a.gathered & TOMO_GATHERED_B) ? gi : fi];
+                        if (a.fidelity == TOMO_FID_KL || a.fidelity == TOMO_FID_RATIO) {
+                            const float ax = val < 1e-8f ? 1e-8f : val;
+                            const float qv = bv / ax;
+                            val = (a.fidelity == TOMO_FID_KL) ? 1.0f - qv : qv;
+                        } else {
+                            val = val - bv;
+                            if (a.ring) val = val + a.ring_scale * a.ring[(size_t)z * a.nu + iu];
+                            if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
+                        }
+                    }
+                    a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
                 }
             }
-            a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
         }
     }
 }

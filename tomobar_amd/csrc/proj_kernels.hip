@@ -516,6 +516,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
         // measured at 384..640-wide detectors (tools/kernel_bench.py): the whole-row form is 7-37 % faster than 256-pixel
         // tiles there as well, so it is considered from 128 pixels up (it used to start at 768)
         constexpr int FP_WIDE_MIN_NU = 128;
+        constexpr double FP_DENSE16_PAYS = 0.75;  // dense form taken when it stages <= 0.75x what whole rows x 8 angles would
         bool done[4] = {false, false, false, false};
         // try_wide: whole-row form for `nc` angles starting at `off_d` of the order table (one stepping class, or the two
         // sign classes of an axis merged); returns 1 if launched, 0 if the 256-pixel tiles are the better choice, < 0 on error
@@ -589,14 +590,102 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                                  std::to_string(kc_w) + " rows/chunk) ";
             return 1;
         };
+        // ---- dense form (round 4): 256 detector pixels x 16 angles per workgroup.  When neighbouring angles of the slope order
+        // are a fraction of a degree apart (BASELINE configs[3]: 1500 angles, no subsets) a 16-angle group's window is hardly
+        // wider than an 8-angle group's, so every staged volume row serves twice the rays: 0.12 staged columns per sample
+        // against 0.18 for whole rows x 8 angles.  Three 256-thread workgroups per CU (12 waves, <= 168 registers).
+        constexpr int FP_A16 = 16;
+        auto dense16_cost = [&](int c, size_t off_c, int nc) -> double {
+            if (nc < 2 * FP_A16) return -1.0;
+            if (s.wbound16[c] < 0)
+                s.wbound16[c] = fp_window_bound(ctx->host_table.data() + s.table_offset, ctx->host_fp_order.data() + off_c, nc,
+                                                ctx->n, ctx->nu, 256, FP_A16);
+            if (s.wbound16[c] > 512) return -1.0;  // two column passes at most
+            const int kc = s.wbound16[c] <= 256 ? 4 : 2;
+            if ((size_t)2 * kc * s.wbound16[c] * 16 + (size_t)a.n * 8 > 64 * 1024) return -1.0;  // three workgroups per CU
+            if (8L * (((long)ceil_div(a.nz, 4) * ceil_div(a.nu, 256) * ceil_div(nc, FP_A16) + 7) / 8) > 0x7fffffffL) return -1.0;
+            return (double)ceil_div(a.nu, 256) * ceil_div(nc, FP_A16) * s.wbound16[c];
+        };
+        auto launch_dense16 = [&](int c, size_t off_c, int nc) -> int {
+            FpTiledArgs t;
+            t.src = (c >> 1) ? a.volT : a.vol;
+            t.tab = a.tab;
+            t.order = ctx->dev_fp_order + off_c;
+            t.n_class = nc;
+            t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
+            t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
+            t.ring = ring; t.ring_scale = ring_scale;
+            t.wpitch = s.wbound16[c];
+#if TOMO_DEV
+            t.probe = g_probe;
+#endif
+            const int passes = ceil_div(t.wpitch, 256);   // 1 or 2
+            const int kc = passes == 1 ? 4 : 2;            // four float4 staging items per thread and chunk either way
+            const size_t smem = (size_t)2 * kc * t.wpitch * 16 + (size_t)a.n * 8;
+            t.nut = ceil_div(a.nu, 256);
+            t.bt = 256;
+            t.ngroups = ceil_div(nc, FP_A16);
+            t.nzb = ceil_div(a.nz, 4);
+            const long blocks = 8L * (((long)t.nzb * t.nut * t.ngroups + 7) / 8);  // (size limits checked in dense16_cost)
+#define FP_D16_LAUNCH(L8, RES)                                                                                         \
+    do {                                                                                                               \
+        if (passes == 1) fp_tiled_kernel<L8, RES, 1, 4, true, 256, FP_A16><<<(unsigned)blocks, 256, smem, st>>>(t);   \
+        else fp_tiled_kernel<L8, RES, 2, 4, true, 256, FP_A16><<<(unsigned)blocks, 256, smem, st>>>(t);                \
+    } while (0)
+            if (b) { if (l8) FP_D16_LAUNCH(true, true); else FP_D16_LAUNCH(false, true); }
+            else   { if (l8) FP_D16_LAUNCH(true, false); else FP_D16_LAUNCH(false, false); }
+#undef FP_D16_LAUNCH
+            if (hipGetLastError() != hipSuccess) return -1;
+            ctx->last_fp_path += "class" + std::to_string(c) + ":dense(256 pixels x 16 angles, " + std::to_string(passes) + " passes) ";
+            return 1;
+        };
         {
             size_t axis_off = s.table_offset;
             const int nut = ceil_div(a.nu, 256);
-            for (int d = 0; d < 2 && g_variant_fp == 0 && a.nu >= FP_WIDE_MIN_NU; ++d) {
+            for (int d = 0; d < 2 && (g_variant_fp == 0 || g_variant_fp == 3) && a.nu >= FP_WIDE_MIN_NU; ++d) {
                 const int nc0 = s.n_class[2 * d], nc1 = s.n_class[2 * d + 1], nc = nc0 + nc1;
                 const size_t off_d = axis_off;
                 axis_off += nc;
                 if (nc == 0) continue;
+                {
+                    // dense form for both sign classes of the axis when it stages clearly less than whole rows x 8 angles would
+                    // (variant 3, dev flavour: whenever it is applicable -- the A/B and parity tests of this form)
+                    const double c0 = nc0 ? dense16_cost(2 * d, off_d, nc0) : 0.0, c1 = nc1 ? dense16_cost(2 * d + 1, off_d + nc0, nc1) : 0.0;
+                    const int nut_w = ceil_div(a.nu, 1024);
+                    const int bt_w = std::min(1024, ceil_div(ceil_div(a.nu, nut_w), 64) * 64);
+                    bool take = c0 >= 0.0 && c1 >= 0.0;
+#ifdef TOMO_FP_NO_DENSE16   // A/B builds only (tools/run_ab.sh)
+                    take = false;
+#endif
+                    if (take && g_variant_fp == 0) {
+                        double rows = 0.0;
+                        if (a.nu <= 1024) {
+                            if (s.wbound_wide[2 * d] < 0)
+                                s.wbound_wide[2 * d] = fp_window_bound(ctx->host_table.data() + s.table_offset, ctx->host_fp_order.data() + off_d,
+                                                                       nc, ctx->n, ctx->nu, bt_w);
+                            rows = (double)nut_w * ceil_div(nc, FP_A) * s.wbound_wide[2 * d];
+                        } else {
+                            for (int h = 0; h < 2; ++h) {
+                                const int nch = h ? nc1 : nc0;
+                                if (nch == 0) continue;
+                                int &wc = s.wbound_wide[2 * d + h];
+                                if (wc < 0)
+                                    wc = fp_window_bound(ctx->host_table.data() + s.table_offset,
+                                                         ctx->host_fp_order.data() + off_d + (h ? nc0 : 0), nch, ctx->n, ctx->nu, bt_w);
+                                rows += (double)nut_w * ceil_div(nch, FP_A) * wc;
+                            }
+                        }
+                        take = (c0 + c1) <= FP_DENSE16_PAYS * rows;
+                    }
+                    if (take) {
+                        const int rc0 = nc0 ? launch_dense16(2 * d, off_d, nc0) : 1;
+                        const int rc1 = nc1 ? launch_dense16(2 * d + 1, off_d + nc0, nc1) : 1;
+                        if (rc0 < 0 || rc1 < 0) return tomo_fail(TOMO_E_INVALID, "forward-projection launch failed (or the problem is too large for one launch)");
+                        done[2 * d] = done[2 * d + 1] = true;
+                        continue;
+                    }
+                }
+                if (g_variant_fp == 3) continue;
                 const double ct0 = (double)nut * ceil_div(nc0, FP_A) * std::max(s.wbound[2 * d], 0);
                 const double ct1 = (double)nut * ceil_div(nc1, FP_A) * std::max(s.wbound[2 * d + 1], 0);
                 if (a.nu <= 1024) {

@@ -46,6 +46,7 @@ struct tomo_subset {
     int n_class[4] = {0, 0, 0, 0};
     int wbound[4] = {-1, -1, -1, -1};
     int wbound_wide[4] = {-1, -1, -1, -1};  // same for 1024-pixel detector tiles
+    int wbound16[4] = {-1, -1, -1, -1};     // same for 256-pixel tiles x 16 angles (dense angle sets)
 };
 
 struct tomo_ctx {
