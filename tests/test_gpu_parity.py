@@ -116,7 +116,7 @@ def test_forward_projection_oblique_windows(oracle, ops, n, na, os_n, variant):
 
 @pytest.mark.dev_variants
 @pytest.mark.parametrize("g", [(6, 300, 300, 400, 0.0, 1), (5, 520, 700, 300, 1.5, 1), (9, 200, 333, 512, "vec", 2),
-                               (4, 1100, 1100, 360, -2.0, 1)])
+                               (4, 1100, 1100, 1000, -2.0, 1)])
 def test_forward_projection_dense_angle_form(oracle, ops, g):
     """The dense-angle form of the forward projector (256 pixels x 16 angles per workgroup, round 4), forced wherever it is
     applicable (fp variant 3, dev flavour): bit for bit against the oracle, plain and with the residual epilogue."""
