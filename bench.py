@@ -51,7 +51,7 @@ LDS_PEAK_BPS = 256.0 * 256 * 2.4e9  # same guide, LDS: ds_read_b128 256 B/clk/CU
 # for the sources it was measured on)
 KERNEL_SOURCES = {
     "pdtv": ["tomobar_amd/csrc/tv_kernels.hip", "tomobar_amd/csrc/pd_zmarch_xk.inl", "tomobar_amd/csrc/pd_zmarch_x2.inl", "tomobar_amd/csrc/pd_zmarch2.inl",
-             "tomobar_amd/csrc/pd_rows2d.inl", "tomobar_amd/csrc/tomo_common.h"],
+             "tomobar_amd/csrc/pd_rows2d.inl"],
     "roftv": ["tomobar_amd/csrc/tv_kernels.hip", "tomobar_amd/csrc/rof_zmarch.inl"],
     "bp": ["tomobar_amd/csrc/proj_kernels.hip", "tomobar_amd/csrc/bp_brick.inl"],
     "fp": ["tomobar_amd/csrc/proj_kernels.hip", "tomobar_amd/csrc/fp_tiled.inl"],
@@ -277,7 +277,10 @@ def live_traffic(dom, args, n, nz, sub):
     what = {"pdtv": ("pdtv22" if getattr(args, "exact_tv", False) else "pdtv0") + ("h" if args.half else ""),
             "roftv": "roftv", "bp": "bp0", "fp": "fp"}[dom]
     key = {"pdtv": ["xk_kernel"], "roftv": ["rof_"], "bp": ["bp_brick"], "fp": ["fp_tiled", "transpose"]}[dom]
-    tmp = tempfile.mkdtemp(prefix="tomo_pmc_", dir="/tmp")
+    try:
+        tmp = tempfile.mkdtemp(prefix="tomo_pmc_", dir="/tmp")
+    except OSError as e:
+        return None, f"no scratch directory for the counter passes: {e!r}"[:160]
     env = dict(os.environ, TMPDIR="/tmp", PMC_PD_ITERS="9")
     got = {}
     try:
@@ -308,7 +311,7 @@ def live_traffic(dom, args, n, nz, sub):
         if dom == "fp":        # one call = two stepping-axis launches + the in-plane transpose; the probe makes two calls
             fs = sum(sum(v) for v in got["FETCH_SIZE"]) / 2.0
             ws = sum(sum(v) for v in got["WRITE_SIZE"]) / 2.0
-            return kib(fs, ws), f"live: rocprofv3 --pmc passes over tools/pmc_probe.py fp {n} {nz} {sub}; per forward projection (2 launches + transpose)"
+            return kib(fs, ws), f"live: rocprofv3 --pmc passes over tools/pmc_probe.py fp {n} {nz} {sub}; per forward projection (its stepping-class launches + the in-plane transpose)"
         f, w = got["FETCH_SIZE"][0][-1], got["WRITE_SIZE"][0][-1]   # steady-state launch: the last one
         return kib(f, w), f"live: rocprofv3 --pmc passes over tools/pmc_probe.py {what} {n} {nz} {sub}; last launch"
     except (AssertionError, IndexError) as e:

@@ -325,7 +325,7 @@ int tomo_fourier_inv(int device, const float *data_dev, float *out_dev, int nz, 
  * host-computed 1 / (1 + lt) instead of the divide: within 1e-5 of the reference, typically 3e-7); binary16 duals
  * (half_precision) and ROF_TV reproduce the reference's roundings in every build (rudin_osher_fatemi_total_variation.cu:51-61).
  * Anything else returns TOMO_E_INVALID: the independent implementations and A/B builds used by tests/ and tools/ (bp 1/2,
- * fp 1/2, pdtv 1/2/3/21, roftv 1..4) and the measurement switches ("probe") exist only in libtomo_mi355x_dev.so
+ * fp 1/2/3, pdtv 1/2/3/21, roftv 1..4) and the measurement switches ("probe") exist only in libtomo_mi355x_dev.so
  * (csrc/Makefile: `make dev`). */
 int tomo_set_variant(const char *kernel, int variant);
 

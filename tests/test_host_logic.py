@@ -28,13 +28,13 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 
 def test_shipped_library_carries_no_ab_variants_or_probes():
-    """the shipped library accepts only its defaults (+ the opt-in relaxed PD_TV arithmetic); the A/B
+    """the shipped library accepts only its defaults (+ the opt-in exact PD_TV roundings, 22); the A/B
     variants and the measurement switches exist in libtomo_mi355x_dev.so alone.  (No kernel runs: tomo_set_variant is host state.)"""
     from tomobar_amd import _lib
     assert _lib.flavour() == "shipped"
     ship = _lib.lib()
     assert ship.tomo_build_flavour() == b"shipped"
-    for name, good, bad in (("bp", (0,), (1, 2, 7)), ("fp", (0,), (1, 2)), ("pdtv", (0, 22), (1, 2, 3, 21, 31)),
+    for name, good, bad in (("bp", (0,), (1, 2, 7)), ("fp", (0,), (1, 2, 3)), ("pdtv", (0, 22), (1, 2, 3, 21, 31)),
                             ("roftv", (0,), (1, 2, 3, 4))):
         for v in bad:
             assert ship.tomo_set_variant(name.encode(), v) == _lib.E_INVALID, (name, v)
@@ -46,7 +46,7 @@ def test_shipped_library_carries_no_ab_variants_or_probes():
     with _lib.use_flavour("dev") as dev:
         assert _lib.flavour() == "dev" and dev is _lib.lib() and dev is not ship
         assert dev.tomo_build_flavour() == b"dev"
-        for name, vs in (("bp", (1, 2)), ("fp", (1, 2)), ("pdtv", (1, 2, 3, 21, 22)), ("roftv", (1, 2, 3, 4)), ("probe", (1, 0))):
+        for name, vs in (("bp", (1, 2)), ("fp", (1, 2, 3)), ("pdtv", (1, 2, 3, 21, 22)), ("roftv", (1, 2, 3, 4)), ("probe", (1, 0))):
             for v in vs:
                 assert dev.tomo_set_variant(name.encode(), v) == _lib.OK, (name, v)
             dev.tomo_set_variant(name.encode(), 0)
@@ -207,6 +207,37 @@ def test_bench_ranks_take_arguments_from_environment(monkeypatch):
     assert (a.gpus, a.n, a.nz, a.strong) == (2, 256, 32, True)
     monkeypatch.delenv("RANK")
     assert bench.parse().gpus == 1   # a plain run ignores a stale variable
+
+
+def test_bench_environment_overrides_and_north_star_footprint(monkeypatch):
+    """A driver that only varies --gpus reaches the other workloads through BENCH_CONFIG / BENCH_STRONG; the north-star
+    block (configs[4], strong scaling) is attempted only when a rank's share fits a 288 GB GPU: from 4 ranks on."""
+    import sys
+    import bench
+    from tomobar_amd.slab import slab_bounds
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    a = bench.parse()
+    assert (a.n, a.nz, a.angles, a.os, a.reg, a.strong) == (1024, 1024, 900, 12, "PD_TV", False) and not a.overridden
+    monkeypatch.setenv("BENCH_CONFIG", "cfg5")
+    monkeypatch.setenv("BENCH_STRONG", "1")
+    a = bench.parse()
+    assert (a.n, a.nz, a.angles, a.os, a.ring, a.strong) == (2560, 2160, 1800, 12, 1e-4, True) and not a.overridden
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "cfg3"])   # an explicit flag wins over the environment
+    assert bench.parse().n == 2048
+    monkeypatch.setenv("BENCH_CONFIG", "nonsense")
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    with pytest.raises(SystemExit):
+        bench.parse()
+    monkeypatch.delenv("BENCH_CONFIG")
+    monkeypatch.delenv("BENCH_STRONG")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "cfg5"])
+    ns = bench.parse()
+    fits = {}
+    for world in (1, 2, 4, 8):
+        share = max(slab_bounds(ns.nz, world, r)[1] - slab_bounds(ns.nz, world, r)[0] for r in range(world))
+        fits[world] = bench.footprint_bytes(ns, share) < 0.9 * 288e9
+    assert fits == {1: False, 2: False, 4: True, 8: True}, fits
 
 
 def test_oracle_thread_team_follows_the_usable_cpus(oracle, monkeypatch):

@@ -603,7 +603,11 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
             if (s.wbound16[c] > 512) return -1.0;  // two column passes at most
             const int kc = s.wbound16[c] <= 256 ? 4 : 2;
             if ((size_t)2 * kc * s.wbound16[c] * 16 + (size_t)a.n * 8 > 64 * 1024) return -1.0;  // three workgroups per CU
-            if (8L * (((long)ceil_div(a.nz, 4) * ceil_div(a.nu, 256) * ceil_div(nc, FP_A16) + 7) / 8) > 0x7fffffffL) return -1.0;
+            const long wgs = (long)ceil_div(a.nz, 4) * ceil_div(a.nu, 256) * ceil_div(nc, FP_A16);
+            if (8L * ((wgs + 7) / 8) > 0x7fffffffL) return -1.0;
+            // a launch per sign class must still fill the chip several times over (768 resident workgroups): on BASELINE
+            // configs[1] (256^3, 360 angles) the form left half the CUs idle -- 542 instead of 702 iterations/s
+            if (wgs < 4 * 768 && g_variant_fp != 3) return -1.0;
             return (double)ceil_div(a.nu, 256) * ceil_div(nc, FP_A16) * s.wbound16[c];
         };
         auto launch_dense16 = [&](int c, size_t off_c, int nc) -> int {

@@ -99,11 +99,12 @@ void tomo_fourier_cache_release(int device);  // cached hipFFT plans of fourier_
 void tomo_fbp_cache_release(int device);      // cached hipFFT plans / filter tables of fbp_filter.hip
 
 // kernel-variant switches (tomo_set_variant).  Two flavours of the library are built from these sources:
-//   libtomo_mi355x.so      (shipped): every kernel class runs its default (variant 0); "pdtv" additionally accepts 3 =
-//                          relaxed arithmetic (v_rsq / hoisted reciprocal, <= 1e-5 from the default).  No measurement
-//                          switches are compiled in: g_probe is the constant 0 and every `probe &` test folds away.
+//   libtomo_mi355x.so      (shipped): every kernel class runs its default (variant 0); "pdtv" additionally accepts 22 =
+//                          the reference's roundings for float32 duals (bit-identical to the oracle; the default is within
+//                          1e-5).  No measurement switches are compiled in: g_probe is the constant 0 and every
+//                          `probe &` test folds away.
 //   libtomo_mi355x_dev.so  (-DTOMO_DEV_VARIANTS; tests and tools/ only): the independent implementations and A/B builds
-//                          (bp 1/2, fp 1/2, pdtv 1/2/21, roftv 1/2/3/4) and the "probe" bits of tools/*_probe.py.
+//                          (bp 1/2, fp 1/2/3, pdtv 1/2/3/21, roftv 1/2/3/4) and the "probe" bits of tools/*_probe.py.
 extern thread_local int g_variant_bp, g_variant_fp, g_variant_pdtv, g_variant_roftv;
 #ifdef TOMO_DEV_VARIANTS
 #define TOMO_DEV 1
