@@ -297,6 +297,27 @@ def test_osem_against_reference_python_loop(oracle, golden_dir, name, pd_arith):
         assert np.array_equal(got, want), np.abs(got - want).max()
 
 
+def test_exact_roundings_key_selects_the_reference_arithmetic_for_one_call(oracle, geom):
+    """``_regularisation_["exact_roundings"] = True`` (an extension of the reference's dictionary): PD_TV with the reference's
+    rounding sequence for this call only -- bit-identical to the oracle without touching tomo_set_variant; the library's
+    switch is back at the default afterwards (the next call is the relaxed build again: within 1e-5, not equal)."""
+    from tomobar_amd import ops
+    os_n = 4
+    rt = make(geom, os_number=os_n)
+    P = oracle.Projector(geom["nz"], geom["n"], geom["n"], geom["angles"], 0.0, os_n)
+    Lc = 2.0e4
+    reg = {"method": "PD_TV", "regul_param": 0.002, "iterations": 9, "methodTV": 0, "PD_LipschitzConstant": 12.0}
+    alg = {"iterations": 2, "lipschitz_const": Lc, "nonnegativity": True, "recon_mask_radius": None}
+    want = oracle.fista(P, geom["sino"], 2, Lc, True, reg)
+    assert ops.get_variant("pdtv") == 0
+    exact = host(rt.FISTA(data_dict(geom), dict(alg), {"method": "PD_TV", "regul_param": 0.002, "iterations": 9,
+                                                      "exact_roundings": True}))
+    assert np.array_equal(exact, want), float(np.abs(exact - want).max())
+    assert ops.get_variant("pdtv") == 0
+    default = host(rt.FISTA(data_dict(geom), dict(alg), {"method": "PD_TV", "regul_param": 0.002, "iterations": 9}))
+    assert rel(default, want) < TOL and not np.array_equal(default, want)
+
+
 @pytest.mark.parametrize("method", ["PD_TV", None])
 def test_fista_repeated_calls_on_one_object_are_bit_identical(oracle, geom, method, pd_arith):
     """the transposed X_t that the momentum kernel leaves in the projector context is a one-shot

@@ -6,7 +6,9 @@ Arrays are ``torch.Tensor`` (float32, device ``cuda:<index>``) where the referen
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -214,5 +216,28 @@ def roftv(data, out, lam, tau, iterations, half):
     return out
 
 
+_variant_state = threading.local()   # mirror of the library's per-thread switches, per flavour: lets `variant()` restore
+
+
 def set_variant(kernel: str, variant: int):
     L.check(L.lib().tomo_set_variant(kernel.encode(), int(variant)))
+    state = getattr(_variant_state, "v", None)
+    if state is None:
+        state = _variant_state.v = {}
+    state[(L.flavour(), kernel)] = int(variant)
+
+
+def get_variant(kernel: str) -> int:
+    """The variant this thread last selected for `kernel` in the current library flavour (0 = default)."""
+    return getattr(_variant_state, "v", {}).get((L.flavour(), kernel), 0)
+
+
+@contextlib.contextmanager
+def variant(kernel: str, value: int):
+    """`with ops.variant("pdtv", 22): ...` -- select a kernel variant for a block and restore what was selected before."""
+    prev = get_variant(kernel)
+    set_variant(kernel, value)
+    try:
+        yield
+    finally:
+        set_variant(kernel, prev)

@@ -18,7 +18,18 @@ from . import ops
 
 
 def prox_regul(self, X: torch.Tensor, _regularisation_: dict, out=None) -> torch.Tensor:
-    """Dispatch on the ``method`` substring exactly like regularisersCuPy.py:16-38."""
+    """Dispatch on the ``method`` substring exactly like regularisersCuPy.py:16-38.
+
+    One key beyond the reference's: ``_regularisation_["exact_roundings"] = True`` runs PD_TV with the rounding sequence of
+    the reference's kernels for float32 duals too (``tomo_set_variant("pdtv", 22)``: bit-identical to the reference
+    arithmetic, 5-16 % slower per launch) for this call; absent / False = the default (within 1e-5)."""
+    if _regularisation_.get("exact_roundings") and "PD_TV" in _regularisation_["method"] and ops.get_variant("pdtv") == 0:
+        with ops.variant("pdtv", 22):
+            return _prox_regul(self, X, _regularisation_, out)
+    return _prox_regul(self, X, _regularisation_, out)
+
+
+def _prox_regul(self, X: torch.Tensor, _regularisation_: dict, out=None) -> torch.Tensor:
     method = _regularisation_["method"]
     slab = getattr(self, "slab", None)
     if slab is not None and X.dim() == 3 and min(X.shape) > 1:
