@@ -340,7 +340,8 @@ def measure(args, env):
     from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
     from tomobar_amd.slab import GHOST, SlabComm, check_slab_split, pd_launch_plan, slab_bounds
     lib = _lib.lib()
-    lib.tomo_set_variant(b"pdtv", 22 if getattr(args, "exact_tv", False) else 0)
+    from tomobar_amd import ops as _ops
+    _ops.set_variant("pdtv", 22 if getattr(args, "exact_tv", False) else 0)
 
     n, na = args.n, args.angles
     if args.strong:
