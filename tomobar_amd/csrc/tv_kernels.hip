@@ -453,6 +453,10 @@ int pd_xk3_launch(const PdArgs &a, int variant, hipStream_t st)
 {
 #if TOMO_DEV
     if (variant == 3) return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 2, 2, true, 10>(a, st);
+    if constexpr (sizeof(T) == 4) {  // workgroup shapes of the shipped relaxed kernel, measurement only (tools/pd_time.py)
+        if (variant == 31) return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 1, 4, true, 10>(a, st);
+        if (variant == 32) return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 4, 1, true, 10>(a, st);
+    }
     if (variant == 21) {
         if constexpr (sizeof(T) == 4) return pd_zmarch_xk_launch<T, NN, AN, 0, 3, 8, 2, 2, true, 10>(a, st);
         else return pd_zmarch_xk_launch<T, NN, AN, 0, 3, 4, 2, 2, true>(a, st);  // 4 rows per lane: the IEEE expansions need the registers

@@ -9,7 +9,11 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 vol = torch.rand((N, N, N), device="cuda")
 out = torch.empty_like(vol)
-for name, variant, half in (("default f32", 0, False), ("exact f32 (22)", 22, False), ("f16 duals", 0, True)):
+cases = [("default f32", 0, False), ("exact f32 (22)", 22, False), ("f16 duals", 0, True)]
+from tomobar_amd import _lib
+if _lib.flavour() == "dev":   # TOMO_MI355X_FLAVOUR=dev: workgroup shapes of the relaxed float32 kernel as well
+    cases += [("relaxed 1x4 waves (31)", 31, False), ("relaxed 4x1 waves (32)", 32, False)]
+for name, variant, half in cases:
     ops.set_variant("pdtv", variant)
     PD_TV_cupy(vol, 0.01, 30, 0, 1, 12.0, 0, half, out=out); torch.cuda.synchronize()
     ts = []
@@ -17,5 +21,5 @@ for name, variant, half in (("default f32", 0, False), ("exact f32 (22)", 22, Fa
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); PD_TV_cupy(vol, 0.01, 30, 0, 1, 12.0, 0, half, out=out); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / 10)
-    print(f"{name:16s} {min(ts):7.3f} ms per three-iteration launch (min of {REPS}), median {sorted(ts)[len(ts)//2]:7.3f}", flush=True)
+    print(f"{name:24s} {min(ts):7.3f} ms per three-iteration launch (min of {REPS}), median {sorted(ts)[len(ts)//2]:7.3f}", flush=True)
 ops.set_variant("pdtv", 0)
