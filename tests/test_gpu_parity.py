@@ -136,6 +136,35 @@ def test_forward_projection_dense_angle_form(oracle, ops, g):
         assert np.array_equal(host(res), (want - b[:, idx]).astype(np.float32)), (g, s)
 
 
+@pytest.mark.dev_variants
+@pytest.mark.parametrize("seed", range(12))
+def test_forward_projection_dense_angle_form_random_geometries(oracle, ops, seed):
+    """Seeded random geometries with MANY angles (130-700: classes of >= 32 angles, windows of a 16-angle group <= 512 columns
+    or not), detector wider / narrower than the grid, rotation-axis offsets, arbitrary angle ranges, subsets: the dense-angle
+    form wherever it applies (fp variant 3; the other forms where it does not), bit for bit against the oracle."""
+    from tomobar_amd.projector import HipTools3D
+    rng = np.random.default_rng(3000 + seed)
+    nz = int(rng.integers(1, 10))
+    n = int(rng.integers(64, 400))
+    nu = int(max(32, n + rng.integers(-n // 3, n // 2 + 1)))
+    na = int(rng.integers(130, 700))
+    start = float(rng.uniform(-np.pi, np.pi))
+    span = float(rng.choice([np.pi, 2 * np.pi, 1.3])) * float(rng.choice([1.0, -1.0]))
+    angles = start + np.linspace(0, span, na, endpoint=False)
+    cor = float(rng.uniform(-0.1, 0.1) * nu) if seed % 3 else np.asarray(rng.uniform(-2, 2, na))
+    os_n = int(rng.choice([1, 1, 2, 3]))
+    P = oracle.Projector(nz, n, nu, angles, cor, os_n)
+    H = HipTools3D(nu, 0, nz, angles, cor, n, "gpu", 0, os_n if os_n > 1 else None)
+    ops.set_variant("fp", 3)
+    vol = rng.standard_normal((nz, n, n)).astype(np.float32)
+    took = []
+    for s in ([None] if os_n == 1 else list(range(os_n))):
+        got = host(H.forward(dev(vol), s))
+        took.append("dense(" in H.kernel_path("fp"))
+        assert np.array_equal(got, P.fp(vol, s)), (seed, s, (nz, n, nu, na, os_n), H.kernel_path("fp"))
+    print("dense form taken:", took, (nz, n, nu, na, os_n))
+
+
 @pytest.mark.parametrize("bp_variants", [(0,), pytest.param((1, 2), marks=DEV)])
 def test_lerp8_mode_and_reference_literals(oracle, ops, bp_variants):
     """tests/test_RecToolsDIRCuPy.py:671-694 of the reference: ones(128,160,160) -> min 67.27458 max 225.27428."""
