@@ -167,6 +167,93 @@ static void run_mix(size_t n, size_t skew)
     hipFree(base); hipFree(din); hipFree(dout);
 }
 
+// PD_TV's ADDRESS STREAM without its arithmetic: the tiling of the shipped K = 3 kernel (pd_zmarch_xk.inl) -- a 256-thread
+// workgroup = 2 x 2 waves, a lane = one column, a wave = 8 rows + 3 halo rows either side and 58 + 6 columns, the
+// workgroup marches a z-chunk plane by plane; per plane a wave loads 14 rows of U, 13 rows of each of three duals and 12
+// rows of the input (dword per lane, rows 4 KB apart) and stores 8 rows of U and of the three duals.  Occupancy is pinned
+// with dynamic LDS: 80 KiB per workgroup = two workgroups per CU = two waves per SIMD, like the kernel; 0 = whatever fits.
+// What this reaches is the ceiling of the kernel's request stream at its own occupancy.
+// MODE bits: 1 = the y-halo rows alias onto the workgroup's own 16 rows (no y over-fetch), 2 = the x-halo lanes alias onto the
+// workgroup's own 116 columns, 4 = non-temporal stores, 8 = non-temporal loads
+template <int MODE>
+__global__ __launch_bounds__(256) void march(const float *const *in, float *const *out, int n, int nz, int gx, int gy, int zchunk,
+                                             int tiles_per_xcd)
+{
+    const int j = (int)blockIdx.x >> 3, xcd = (int)blockIdx.x & 7;
+    const int tq = xcd * tiles_per_xcd + (j % tiles_per_xcd), chunk = j / tiles_per_xcd;
+    if (tq >= gx * gy) return;
+    const int xb = tq % gx, yb = tq / gx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = min(max((xb * 2 + (wave & 1)) * 58 - 3 + lane, 0), n - 1);
+    if (MODE & 2) x = min(max(x, xb * 116), min(xb * 116 + 115, n - 1));
+    const int y0 = (yb * 2 + (wave >> 1)) * 8;
+    const int ylo = (MODE & 1) ? yb * 16 : 0, yhi = (MODE & 1) ? min(yb * 16 + 15, n - 1) : n - 1;
+    const int z0 = chunk * zchunk, z1 = min(z0 + zchunk, nz);
+    const bool emit = lane >= 3 && lane <= 60;
+    auto ld = [](const float *p) { return (MODE & 8) ? __builtin_nontemporal_load(p) : *p; };
+    for (int z = max(z0 - 3, 0); z < z1; ++z) {
+        const size_t pl = (size_t)z * n * n;
+        float acc = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 14; ++r) {
+            const size_t o = pl + (size_t)min(max(y0 + r - 3, ylo), yhi) * n + x;
+            acc += ld(in[0] + o);
+            if (r < 13) acc += ld(in[1] + o) + ld(in[2] + o) + ld(in[3] + o);
+            if (r >= 1 && r < 13) acc += ld(in[4] + o);
+        }
+        __syncthreads();
+        if (emit && z >= z0) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int y = y0 + r;
+                if (y < n) {
+                    const size_t o = pl + (size_t)y * n + x;
+                    if (MODE & 4) {
+                        __builtin_nontemporal_store(acc, out[0] + o); __builtin_nontemporal_store(acc, out[1] + o);
+                        __builtin_nontemporal_store(acc, out[2] + o); __builtin_nontemporal_store(acc, out[3] + o);
+                    } else { out[0][o] = acc; out[1][o] = acc; out[2][o] = acc; out[3][o] = acc; }
+                }
+            }
+        }
+    }
+}
+
+static void run_march(int n, int nz, size_t skew)
+{
+    const size_t vox = (size_t)n * n * nz, per = vox * 4 + skew;
+    float *base;
+    if (hipMalloc(&base, per * 9 + 4096) != hipSuccess) { printf("alloc failed\n"); return; }
+    hipMemset(base, 0, per * 9);
+    const float *hin[5]; float *hout[4];
+    for (int k = 0; k < 5; ++k) hin[k] = (const float *)((char *)base + per * k);
+    for (int k = 0; k < 4; ++k) hout[k] = (float *)((char *)base + per * (5 + k));
+    const float **din; float **dout;
+    hipMalloc(&din, sizeof(hin)); hipMalloc(&dout, sizeof(hout));
+    hipMemcpy(din, hin, sizeof(hin), hipMemcpyHostToDevice);
+    hipMemcpy(dout, hout, sizeof(hout), hipMemcpyHostToDevice);
+    const int gx = ((n + 57) / 58 + 1) / 2, gy = (n + 15) / 16, tiles_per_xcd = (gx * gy + 7) / 8;
+    auto go = [&](auto kern, const char *what, int lds_kib, int chunks) {
+        const int zchunk = (nz + chunks - 1) / chunks;
+        const unsigned blocks = 8u * tiles_per_xcd * chunks;
+        const size_t dyn = (size_t)lds_kib * 1024;
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        const double ms = time_ms([&] { kern<<<blocks, 256, dyn>>>(din, dout, n, nz, gx, gy, zchunk, tiles_per_xcd); }, 3);
+        char name[128];
+        snprintf(name, sizeof name, "PD stream %s, %d KiB LDS/WG, %d chunks", what, lds_kib, chunks);
+        report(name, 256, (int)blocks, ms, 36.0 * vox);
+    };
+    for (int lds_kib : {80, 40, 0})
+        for (int chunks : {32, 16}) go(march<0>, "as the kernel", lds_kib, chunks);
+    go(march<1>, "y halo aliased", 80, 32);
+    go(march<2>, "x halo aliased", 80, 32);
+    go(march<3>, "no over-fetch (x+y aliased)", 80, 32);
+    go(march<3>, "no over-fetch (x+y aliased)", 0, 32);
+    go(march<4>, "nt stores", 80, 32);
+    go(march<8>, "nt loads", 80, 32);
+    go(march<12>, "nt loads + stores", 80, 32);
+    hipFree(base); hipFree(din); hipFree(dout);
+}
+
 int main(int argc, char **argv)
 {
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -233,5 +320,7 @@ int main(int argc, char **argv)
     run_mix<5, 4, 1>(n, 69888);
     run_mix<2, 1, 4>(n, 69888);
     run_mix<2, 1, 1>(n, 69888);
+    printf("---- PD_TV's address stream (tiling, row strides, halo re-reads) without its arithmetic, 1024^3; GB/s = COMPULSORY 36 B/voxel / time\n");
+    run_march(1024, 1024, 69888);
     return 0;
 }
