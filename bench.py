@@ -534,6 +534,9 @@ def measure(args, env):
         }
         if halo is not None:
             line["halo"] = halo
+        placed = _ops.placement_last()   # where the library put its largest scratch arena ("placement")
+        if placed is not None:
+            line["placement"] = placed
         return line, sino, lc
     return None, sino, lc
 

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* raised whenever an entry point is added or a signature changes (tomobar_amd/_lib.py checks it at load) */
-#define TOMO_ABI_VERSION 3
+#define TOMO_ABI_VERSION 4
 
 enum {
     TOMO_OK = 0,
@@ -235,6 +235,16 @@ int tomo_roftv(int device, const float *in_dev, float *out_dev, int dx, int dy, 
 size_t tomo_pdtv_scratch_bytes(int dx, int dy, int dz, int nd, int half);
 size_t tomo_roftv_scratch_bytes(int dx, int dy, int dz, int nd);
 int tomo_release_scratch(int device);
+/* Placement of the scratch arenas (no reference counterpart: CuPy's memory pool hands out whatever block comes next).
+ * On MI355X the speed of the plane-marching TV kernels depends on where in HBM their arrays lie (PD_TV launch at 1024^3:
+ * 10.1 ms with the arena in one block, 9.1-9.3 ms in another of the same process), so an arena of
+ * >= 1 GiB is chosen among up to `tries` candidate allocations held at once, each scored by a ~7 ms z-march probe; the
+ * rest are freed again.  Default 4 (environment TOMO_MI355X_PLACE_TRIES), 1 = plain hipMalloc.  Candidates are only
+ * taken while the device keeps 4 GiB free.
+ * tomo_placement_last reports the most recent search of this process: returns the number of candidates scored
+ * (0 = none yet), *bytes the block size, *chosen the index kept, scores_GBps[i] the probe rate of candidate i. */
+int tomo_set_placement_tries(int tries);
+int tomo_placement_last(size_t *bytes, int *chosen, double *scores_GBps, int capacity);
 
 /* Slab (multi-GPU) form of one PD-TV iteration on arrays that carry ghost planes:
  *   every array pointer addresses [has_lo + nz_local + has_hi][dy][dx]; the planes at either end are

@@ -285,10 +285,14 @@ def test_pdtv_default_arithmetic_vs_oracle(oracle, ops, shape):
     x = (rng.random(shape) * 0.3 + (np.indices(shape)[-1] > shape[-1] // 2)).astype(np.float32)
     for half in (False, True):
         for mtv in (0, 1):
-            for nn in (0, 1):
-                xi = (x - 0.6).astype(np.float32) if nn else x
+            # (nonneg, negative values in the data): without the clip negative iterates must pass through untouched -- the
+            # relaxed float32 kernel is ONE instantiation whose clip threshold is an argument (0 or -inf)
+            for nn, shifted in ((0, False), (0, True), (1, True)):
+                xi = (x - 0.6).astype(np.float32) if shifted else x
                 want = oracle.pd_tv(xi, 0.04, 11, mtv, nn, 8.0, half)
                 got = host(PD_TV_cupy(dev(xi), 0.04, 11, mtv, nn, 8.0, 0, half))
+                if shifted and not nn:
+                    assert (got < 0).any() and (want < 0).any()
                 if half:
                     assert np.array_equal(got, want), (shape, mtv, nn)
                     continue
@@ -505,6 +509,38 @@ def test_tv_large_odd_shapes(oracle, ops, seed, pd_variants):
     want_rof = oracle.rof_tv(x, lam, iters, 0.004, half)
     got = host(ROF_TV_cupy(xd, lam, iters, 0.004, 0, half))
     assert np.array_equal(got, want_rof), ("rof", shape, iters, half, np.abs(got - want_rof).max())
+
+
+def test_scratch_arena_placement_search(oracle, ops):
+    """The library picks its large scratch arenas among several candidate allocations scored by a z-march probe (on MI355X
+    the same PD_TV launch runs 10 % faster or slower depending on where its arena lies).  The search
+    must be invisible in the results: same bits with it on (3 candidates) and off, and the report must describe it."""
+    from tomobar_amd import _lib
+    from tomobar_amd.regularisersCuPy import PD_TV_cupy
+    ops.set_variant("pdtv", 22)
+    L = _lib.lib()
+    shape = (40, 2048, 2048)                     # 8 work arrays of 0.67 GB: an arena of 5.4 GB
+    rng = np.random.default_rng(11)
+    x = (rng.random(shape) * 0.3 + (np.indices(shape)[-1] > shape[-1] // 2)).astype(np.float32)
+    xd = dev(x)
+    got = {}
+    try:
+        for tries in (3, 1):
+            _lib.check(L.tomo_release_scratch(0))
+            ops.set_placement_tries(tries)
+            got[tries] = host(PD_TV_cupy(xd, 0.04, 6, 0, 1, 8.0, 0, False))
+            if tries == 3:
+                rep = ops.placement_last()
+                assert rep is not None and rep["bytes"] == L.tomo_pdtv_scratch_bytes(shape[2], shape[1], shape[0], 3, 0)
+                assert 1 <= len(rep["scores_GBps"]) <= 3 and 0 <= rep["chosen"] < len(rep["scores_GBps"])
+                assert all(500.0 < s < 8000.0 for s in rep["scores_GBps"]), rep      # a z-march over HBM
+                assert rep["scores_GBps"][rep["chosen"]] == max(rep["scores_GBps"])
+    finally:
+        ops.set_placement_tries(4)
+        _lib.check(L.tomo_release_scratch(0))
+    assert np.array_equal(got[3], got[1])
+    want = oracle.pd_tv(x[:14], 0.04, 6, 0, 1, 8.0, False)   # the oracle on a slab: 6 iterations reach 6 planes up, 8 of 14 are exact
+    assert np.array_equal(got[3][:8], want[:8])
 
 
 @pytest.mark.parametrize("shape,iters", [((1023, 2049), 7), ((2500, 777), 30), ((64, 5000), 4), ((3000, 61), 5)])

@@ -56,6 +56,23 @@ def test_shipped_library_carries_no_ab_variants_or_probes():
     assert os.path.getsize(_lib.LIB_PATHS["shipped"]) < os.path.getsize(_lib.LIB_PATHS["dev"])
 
 
+def test_placement_controls_are_host_state():
+    """Arena placement search (include/tomo_mi355x.h, tomo_set_placement_tries / tomo_placement_last): the try count is
+    validated host state, and before any arena of >= 1 GiB exists the report is empty.  (No kernel runs here.)"""
+    import ctypes as C
+    from tomobar_amd import _lib
+    L = _lib.lib()
+    for bad in (0, -1, 9, 100):
+        assert L.tomo_set_placement_tries(bad) == _lib.E_INVALID, bad
+        assert b"placement tries" in L.tomo_last_error()
+    for good in (1, 8, 4):
+        assert L.tomo_set_placement_tries(good) == _lib.OK
+    nbytes, chosen, scores = C.c_size_t(7), C.c_int(7), (C.c_double * 8)()
+    assert L.tomo_placement_last(C.byref(nbytes), C.byref(chosen), scores, 8) == 0
+    assert nbytes.value == 0 and chosen.value == -1
+    assert L.tomo_placement_last(None, None, None, 0) == 0
+
+
 def test_no_gpu_means_loud_failure():
     """The product path has no CPU fallback: without a device every constructor raises."""
     if torch.cuda.is_available():

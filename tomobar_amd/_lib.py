@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtomo_mi355x.so")
 
 OK, E_INVALID, E_RUNTIME, E_NOMEM, E_NODEVICE = 0, 1, 2, 3, 4
-ABI_VERSION = 3  # TOMO_ABI_VERSION of include/tomo_mi355x.h (tests/test_host_logic.py keeps the two in step)
+ABI_VERSION = 4  # TOMO_ABI_VERSION of include/tomo_mi355x.h (tests/test_host_logic.py keeps the two in step)
 FLAG_LERP8 = 1
 FID = {"LS": 0, "PWLS": 1, "KL": 2, "RATIO": 3}
 
@@ -79,6 +79,8 @@ SIGNATURES = {
     "tomo_pdtv_scratch_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "tomo_roftv_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "tomo_release_scratch": (_i, [_i]),
+    "tomo_set_placement_tries": (_i, [_i]),
+    "tomo_placement_last": (_i, [C.POINTER(C.c_size_t), C.POINTER(_i), C.POINTER(C.c_double), _i]),
     "tomo_pdtv_iter_slab": (_i, [_i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i,
                                  _f, _f, _f, _f, _i, _i, _i, _vp]),
     "tomo_pdtv_pair_slab": (_i, [_i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i,

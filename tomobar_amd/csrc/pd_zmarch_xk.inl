@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(2)
                         uu[k] = (s == 0) ? U0c[i] : Ur[s][1][i];
                         in4[k] = InS[i];
                     }
-                    pd_primal_block<FAST, DB>(uo, uu, in4, dv, a.tau, a.lt, a.inv1lt, a.theta, NONNEG);
+                    pd_primal_block<FAST, DB>(uo, uu, in4, dv, a.tau, a.lt, a.inv1lt, a.theta, NONNEG, (FAST == 1 && sizeof(T) == 4) ? a.nn_thr : 0.0f);
 #pragma unroll
                     for (int k = 0; k < DB; ++k) {
                         if (rb + k <= Q1) {

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <initializer_list>
 #include <map>
@@ -277,6 +278,131 @@ struct arena_key {
 static std::mutex g_arena_mu;
 static std::map<arena_key, arena_t> g_arenas;
 
+// ---- placement of large scratch blocks (round 4).  On MI355X the speed of a plane-marching kernel depends on WHERE in HBM
+// its arrays were allocated: the same PD_TV launch on the same volume takes 10.1 ms with its scratch arena in one block of
+// device memory and 9.1-9.3 ms in another (same process, same kernel, profiles/r4z_pd_arena_placement.txt); a flat copy does
+// not see the difference (6.1-6.3 TB/s everywhere), a z-march over one array of 4 MB planes does (4.9 vs 5.3 TB/s per 8.6 GB
+// chunk, two levels, roughly a quarter of the device in the slow one and a different quarter in every process).  So a block
+// of >= 1 GiB is chosen among up to `tries` candidate allocations held at the same time: each is scored with a z-march
+// probe over the whole block (~7 ms per 34 GB), the search stops at the first candidate that beats an earlier one by 5 %
+// (two levels: that one is in the fast class), the best is kept and the others are freed.  TOMO_MI355X_PLACE_TRIES=1 (or
+// tomo_set_placement_tries(1)) turns the search off; candidates are only taken while the device has room for them.
+namespace {
+// one array of planes of 1024 x 1024 floats: a workgroup (2 x 2 waves) owns 128 columns x 16 rows (+3 halo rows either side)
+// and walks the planes of its z-chunk, reading 14 rows per wave and plane from the first half of the block and writing 8 into
+// the second half -- the access shape of the TV kernels with one input and one output stream
+__global__ __launch_bounds__(256) void place_probe_kernel(const float *__restrict__ a, float *__restrict__ b, int nz, int zchunk)
+{
+    const int n = 1024, gx = 8, gy = 64;
+    const int tile = (int)blockIdx.x % (gx * gy), chunk = (int)blockIdx.x / (gx * gy);
+    const int xb = tile % gx, yb = tile / gx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = xb * 128 + (wave & 1) * 64 + lane, y0 = yb * 16 + (wave >> 1) * 8;
+    const int z1 = min((chunk + 1) * zchunk, nz);
+    for (int z = chunk * zchunk; z < z1; ++z) {
+        const size_t pl = (size_t)z * n * n;
+        float s = 0.0f;
+#pragma unroll
+        for (int r = -3; r < 11; ++r) s += a[pl + (size_t)min(max(y0 + r, 0), n - 1) * n + x];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) b[pl + (size_t)(y0 + r) * n + x] = s;
+    }
+}
+constexpr size_t PLACE_MIN_BYTES = (size_t)1 << 30;
+constexpr size_t PLACE_HEADROOM = (size_t)4 << 30;  // left free on the device while candidates are held
+constexpr int PLACE_MAX_TRIES = 8;
+int g_place_tries = -1;
+struct place_rec { size_t bytes = 0; int tries = 0, chosen = -1; double score[PLACE_MAX_TRIES] = {0}; } g_place_last;
+
+int placement_tries()
+{
+    if (g_place_tries < 0) {
+        const char *e = std::getenv("TOMO_MI355X_PLACE_TRIES");
+        const int v = e ? std::atoi(e) : 4;
+        g_place_tries = v < 1 ? 1 : (v > PLACE_MAX_TRIES ? PLACE_MAX_TRIES : v);
+    }
+    return g_place_tries;
+}
+
+// GB/s of the probe over the block (min of two passes after a warm-up); 0 on any error
+double place_score(void *p, size_t bytes, hipStream_t st)
+{
+    const int nz = (int)(bytes / 2 / ((size_t)4 << 20));
+    if (nz < 16) return 0.0;
+    const int chunks = 16, zchunk = (nz + chunks - 1) / chunks;
+    const float *a = (const float *)p;
+    float *b = (float *)((char *)p + (size_t)nz * ((size_t)4 << 20));
+    hipEvent_t e[3];
+    for (auto &x : e) if (hipEventCreateWithFlags(&x, hipEventDefault) != hipSuccess) return 0.0;
+    place_probe_kernel<<<512 * chunks, 256, 0, st>>>(a, b, nz, zchunk);
+    double best = 0.0;
+    bool ok = true;
+    for (int r = 0; r < 2 && ok; ++r) {
+        ok = hipEventRecord(e[r], st) == hipSuccess;
+        place_probe_kernel<<<512 * chunks, 256, 0, st>>>(a, b, nz, zchunk);
+        ok = ok && hipEventRecord(e[r + 1], st) == hipSuccess && hipEventSynchronize(e[r + 1]) == hipSuccess;
+        float ms = 0.0f;
+        ok = ok && hipEventElapsedTime(&ms, e[r], e[r + 1]) == hipSuccess && ms > 0.0f;
+        if (ok) best = std::max(best, 2.0 * nz * (double)((size_t)4 << 20) / ms / 1e6);
+    }
+    for (auto &x : e) (void)hipEventDestroy(x);
+    return ok ? best : 0.0;
+}
+
+int placed_malloc(hipStream_t st, size_t bytes, void **out)
+{
+    const int tries = placement_tries();
+    if (bytes < PLACE_MIN_BYTES || tries <= 1) {
+        TOMO_HIP(hipMalloc(out, bytes));
+        return TOMO_OK;
+    }
+    void *cand[PLACE_MAX_TRIES];
+    place_rec rec;
+    rec.bytes = bytes;
+    double lo = 0.0;
+    for (int t = 0; t < tries; ++t) {
+        if (t > 0) {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bytes + PLACE_HEADROOM) break;
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (t == 0) return tomo_fail(TOMO_E_NOMEM, "hipMalloc of %zu bytes of scratch failed", bytes);
+            break;
+        }
+        cand[t] = p;
+        rec.score[t] = place_score(p, bytes, st);
+        rec.tries = t + 1;
+        if (rec.chosen < 0 || rec.score[t] > rec.score[rec.chosen]) rec.chosen = t;
+        lo = (t == 0) ? rec.score[t] : std::min(lo, rec.score[t]);
+        if (t >= 1 && rec.score[rec.chosen] >= 1.05 * lo) break;  // two levels: this one is in the fast class
+    }
+    for (int t = 0; t < rec.tries; ++t)
+        if (t != rec.chosen) (void)hipFree(cand[t]);
+    *out = cand[rec.chosen];
+    g_place_last = rec;
+    return TOMO_OK;
+}
+}  // namespace
+
+extern "C" int tomo_set_placement_tries(int tries)
+{
+    TOMO_REQUIRE(tries >= 1 && tries <= PLACE_MAX_TRIES, "placement tries must be 1 .. %d", PLACE_MAX_TRIES);
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    g_place_tries = tries;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_placement_last(size_t *bytes, int *chosen, double *scores_GBps, int capacity)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    if (bytes) *bytes = g_place_last.bytes;
+    if (chosen) *chosen = g_place_last.chosen;
+    for (int t = 0; scores_GBps && t < capacity && t < g_place_last.tries; ++t) scores_GBps[t] = g_place_last.score[t];
+    return g_place_last.tries;
+}
+
 int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void **out)
 {
     std::lock_guard<std::mutex> lk(g_arena_mu);
@@ -288,7 +414,8 @@ int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void 
             a.ptr = nullptr;
             a.bytes = 0;
         }
-        TOMO_HIP(hipMalloc(&a.ptr, bytes));
+        const int rc = placed_malloc(stream, bytes, &a.ptr);
+        if (rc != TOMO_OK) { a.ptr = nullptr; return rc; }
         a.bytes = bytes;
     }
     *out = a.ptr;

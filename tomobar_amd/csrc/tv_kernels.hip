@@ -202,6 +202,7 @@ struct PdArgs {
     float inv1lt;     // 1 / (1 + lt), relaxed-arithmetic kernels only
     int p_in_zero = 0;   // pd_zmarch_xk: the input duals are all zero (first launch of a prox): do not read them
     int p_out_skip = 0;  // pd_zmarch_xk: do not store the output duals (last launch of a prox)
+    float nn_thr = 0.0f; // pd_zmarch_xk, relaxed float32 build: iterates below this are clipped to 0 (0 = nonnegativity, -inf = none)
 #if TOMO_DEV
     int probe = 0;       // measurement only (tools/pd_halo_probe.py): 1 = alias the y halo rows, 2 = the x halo lanes onto the workgroup's own tile, 4 = every plane access goes to plane 0 (cache-resident: what the kernel costs without HBM)
 #else
@@ -373,10 +374,10 @@ __device__ __forceinline__ void pd_dual_block(float (&p)[NB][3], const float (&g
 
 template <int FAST>
 __device__ __forceinline__ float pd_primal_t(float u_in, float input, float div, float tau, float lt, float inv1lt,
-                                             float theta, bool nonneg)
+                                             float theta, bool nonneg, float nn_thr = 0.0f)
 {
     if (FAST == 0) return pd_primal(u_in, input, div, tau, lt, theta, nonneg);
-    const float u = (nonneg && u_in < 0.0f) ? 0.0f : u_in;
+    const float u = (nonneg && u_in < nn_thr) ? 0.0f : u_in;
     float t = fmaf(-tau, div, u);
     t = fmaf(lt, input, t);
     float nu = t * inv1lt;
@@ -388,7 +389,7 @@ __device__ __forceinline__ float pd_primal_t(float u_in, float input, float div,
 template <int FAST, int NB>
 __device__ __forceinline__ void pd_primal_block(float (&out)[NB], const float (&u_in)[NB], const float (&input)[NB],
                                                 const float (&div)[NB], float tau, float lt, float inv1lt, float theta,
-                                                bool nonneg)
+                                                bool nonneg, float nn_thr = 0.0f)
 {
     if constexpr (FAST == 0) {
 #pragma unroll
@@ -396,7 +397,7 @@ __device__ __forceinline__ void pd_primal_block(float (&out)[NB], const float (&
     } else {
         float u[NB], t[NB], nu[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) u[k] = (nonneg && u_in[k] < 0.0f) ? 0.0f : u_in[k];
+        for (int k = 0; k < NB; ++k) u[k] = (nonneg && u_in[k] < nn_thr) ? 0.0f : u_in[k];
 #pragma unroll
         for (int k = 0; k < NB; ++k) t[k] = fmaf(-tau, div[k], u[k]);
 #pragma unroll
@@ -463,7 +464,15 @@ int pd_xk3_launch(const PdArgs &a, int variant, hipStream_t st)
     }
 #endif
     if (variant == 22 || pd_default_is_exact<T>()) return pd_zmarch_xk_launch<T, NN, AN, 2, 3, 8, 2, 2, true, 10>(a, st);
-    return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 2, 2, true, 10>(a, st);
+    // relaxed float32: ONE instantiation per TV type serves both settings of `nonneg` -- the clip threshold is a kernel
+    // argument (0 or -inf; "u < -inf" is never true, so the iterate passes through exactly as the code without the test
+    // would leave it).  The separate no-clip instantiation of the isotropic kernel allocated 256 registers with 154 spilled
+    // and ran 15 % slower than the one with the test (11.9 vs 10.4 ms per launch), and with the threshold in a scalar register
+    // the compiler's schedule of the clipping kernel itself is 2.8 % faster (profiles/r4y_pd_instantiations.txt).  The exact
+    // builds keep their two instantiations: there the no-clip one is the faster by 3 %.
+    PdArgs b = a;
+    b.nn_thr = NN ? 0.0f : -__builtin_inff();
+    return pd_zmarch_xk_launch<T, true, AN, 1, 3, 8, 2, 2, true, 10>(b, st);
 }
 
 template <typename T, bool NN, bool AN>

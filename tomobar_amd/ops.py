@@ -232,6 +232,23 @@ def get_variant(kernel: str) -> int:
     return getattr(_variant_state, "v", {}).get((L.flavour(), kernel), 0)
 
 
+def set_placement_tries(tries: int):
+    """Candidate allocations the library scores when it places a scratch arena of >= 1 GiB (include/tomo_mi355x.h,
+    tomo_set_placement_tries; default 4 or TOMO_MI355X_PLACE_TRIES; 1 = plain hipMalloc)."""
+    L.check(L.lib().tomo_set_placement_tries(int(tries)))
+
+
+def placement_last():
+    """The library's most recent arena placement search: {"bytes", "chosen", "scores_GBps"} or None if none ran yet."""
+    import ctypes as C
+    nbytes, chosen = C.c_size_t(0), C.c_int(-1)
+    scores = (C.c_double * 8)()
+    n = L.lib().tomo_placement_last(C.byref(nbytes), C.byref(chosen), scores, 8)
+    if n <= 0:
+        return None
+    return {"bytes": int(nbytes.value), "chosen": int(chosen.value), "scores_GBps": [round(float(scores[i]), 1) for i in range(n)]}
+
+
 @contextlib.contextmanager
 def variant(kernel: str, value: int):
     """`with ops.variant("pdtv", 22): ...` -- select a kernel variant for a block and restore what was selected before."""

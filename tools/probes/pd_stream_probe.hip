@@ -8,6 +8,8 @@
 // Rate = COMPULSORY bytes (36 B per voxel) / time.  build: hipcc --offload-arch=gfx950 -O3 -w -o _build/pd_stream_probe pd_stream_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 
@@ -282,9 +284,157 @@ static void go_share(int lds_kib, int chunks)
     fflush(stdout);
 }
 
-int main()
+// "place": does the speed of the stream depend on WHERE the arrays were allocated?  Several arenas held at once, the same
+// stream (the kernel's tiling, halo included) timed on each, twice.
+static int placement(int narena)
 {
+    const int n = 1024, nz = 1024;
+    g_vox = (size_t)n * n * nz;
+    const size_t per = g_vox * 4 + 69888;
+    g.n = n; g.nz = nz;
+    std::vector<char *> bases;
+    for (int k = 0; k < narena; ++k) {
+        char *b;
+        if (hipMalloc(&b, per * 9 + 4096) != hipSuccess) { printf("arena %d: alloc failed\n", k); break; }
+        hipMemset(b, 0, per * 9);
+        bases.push_back(b);
+    }
+    size_t fr, tot; hipMemGetInfo(&fr, &tot);
+    printf("%zu arenas of %.1f GB held, %.1f of %.1f GB free\n", bases.size(), per * 9 / 1e9, fr / 1e9, tot / 1e9);
+    for (int rep = 0; rep < 2; ++rep)
+        for (size_t k = 0; k < bases.size(); ++k) {
+            for (int q = 0; q < 5; ++q) g.in[q] = (const float *)(bases[k] + per * q);
+            for (int q = 0; q < 4; ++q) g.out[q] = (float *)(bases[k] + per * (5 + q));
+            printf("arena %zu at %p: ", k, (void *)bases[k]);
+            go<2, 2, 8, 1, true, false>(80, 32, 0);
+        }
+    return 0;
+}
+
+// "ballast B": B GB allocated first, then an arena, then the ballast is freed and a second arena allocated: which is fast?
+static int ballast(double gb)
+{
+    const int n = 1024, nz = 1024;
+    g_vox = (size_t)n * n * nz;
+    const size_t per = g_vox * 4 + 69888;
+    g.n = n; g.nz = nz;
+    auto run = [&](const char *name, char *b) {
+        for (int q = 0; q < 5; ++q) g.in[q] = (const float *)(b + per * q);
+        for (int q = 0; q < 4; ++q) g.out[q] = (float *)(b + per * (5 + q));
+        printf("%-44s at %p: ", name, (void *)b);
+        go<2, 2, 8, 1, true, false>(80, 32, 0);
+    };
+    std::vector<char *> bal;
+    for (double left = gb; left > 0; left -= 8.0) {  // 8 GB pieces
+        char *p; if (hipMalloc(&p, (size_t)8e9) != hipSuccess) break;
+        hipMemset(p, 0, (size_t)8e9); bal.push_back(p);
+    }
+    char *a1, *a2, *a3;
+    hipMalloc(&a1, per * 9 + 4096); hipMemset(a1, 0, per * 9);
+    run("arena allocated behind the ballast", a1);
+    for (char *p : bal) hipFree(p);
+    hipDeviceSynchronize();
+    run("same arena, ballast freed", a1);
+    hipMalloc(&a2, per * 9 + 4096); hipMemset(a2, 0, per * 9);
+    run("second arena, allocated after the free", a2);
+    hipMalloc(&a3, per * 9 + 4096); hipMemset(a3, 0, per * 9);
+    run("third arena", a3);
+    run("first arena again", a1);
+    return 0;
+}
+
+// "skew": inside ONE allocation, the nine arrays at different relative offsets (array k starts at k * (4 GiB + skew)); twice,
+// on the first and on a later arena of the process
+static int skews()
+{
+    const int n = 1024, nz = 1024;
+    g_vox = (size_t)n * n * nz;
+    g.n = n; g.nz = nz;
+    const size_t room = g_vox * 4 + (64u << 20);
+    std::vector<char *> ar;
+    for (int k = 0; k < 5; ++k) { char *b; if (hipMalloc(&b, room * 9) != hipSuccess) break; hipMemset(b, 0, room * 9); ar.push_back(b); }
+    const long sk[] = {0, 256, 4096, 69888, 65536 + 4096 + 256, 1 << 20, (1 << 20) + 69888, 3 << 20, (5 << 20) + 4096 * 3 + 512, 17 * 4096 + 128, 2097152 + 69888, 33554432 + 69888};
+    for (size_t w : {(size_t)0, ar.size() - 1})
+        for (long s : sk) {
+            const size_t per = g_vox * 4 + (size_t)s;
+            for (int q = 0; q < 5; ++q) g.in[q] = (const float *)(ar[w] + per * q);
+            for (int q = 0; q < 4; ++q) g.out[q] = (float *)(ar[w] + per * (5 + q));
+            printf("arena %zu, skew %9ld B: ", w, s);
+            go<2, 2, 8, 1, true, false>(80, 32, 0);
+        }
+    return 0;
+}
+
+// "mixarena": device memory carved into 4.4 GB pieces in allocation order, each scored alone with a one-array z-march (first
+// half -> second half); then PD_TV's stream with its nine arrays taken from the nine FASTEST pieces, the nine SLOWEST, and nine
+// spread evenly over the allocation order.  Is the speed a property of each piece that adds up?
+__global__ __launch_bounds__(256) void zmarch1(const float *__restrict__ a, float *__restrict__ b, int nz, int zchunk)
+{
+    const int n = 1024, gx = 8, gy = 64;
+    const int tile = blockIdx.x % (gx * gy), chunk = blockIdx.x / (gx * gy);
+    const int xb = tile % gx, yb = tile / gx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = xb * 128 + (wave & 1) * 64 + lane, y0 = yb * 16 + (wave >> 1) * 8;
+    const int z1 = min((chunk + 1) * zchunk, nz);
+    for (int z = chunk * zchunk; z < z1; ++z) {
+        const size_t pl = (size_t)z * n * n;
+        float s = 0.0f;
+#pragma unroll
+        for (int r = -3; r < 11; ++r) s += a[pl + (size_t)min(max(y0 + r, 0), n - 1) * n + x];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) b[pl + (size_t)(y0 + r) * n + x] = s;
+    }
+}
+static int mixarena()
+{
+    const int n = 1024, nz = 1024;
+    g_vox = (size_t)n * n * nz;
+    g.n = n; g.nz = nz;
+    const size_t piece = g_vox * 4 + (1u << 20);
+    std::vector<char *> pc;
+    for (;;) {
+        size_t fr, tot; hipMemGetInfo(&fr, &tot);
+        if (fr < piece + (size_t)8e9) break;
+        char *p; if (hipMalloc(&p, piece) != hipSuccess) break;
+        hipMemset(p, 0, piece); pc.push_back(p);
+    }
+    std::vector<std::pair<double, int>> sc;
+    for (size_t k = 0; k < pc.size(); ++k) {
+        const double ms = time_ms([&] { zmarch1<<<512 * 16, 256>>>((const float *)pc[k], (float *)(pc[k] + piece / 2), 512, 32); });
+        const double gbs = 2.0 * 512 * (4u << 20) / ms / 1e6;
+        // the same piece in 1 GiB quarters (128 planes in, 128 out)
+        double q[4];
+        for (int i = 0; i < 4; ++i) {
+            const char *b = pc[k] + (size_t)i * (1u << 30);
+            const double m2 = time_ms([&] { zmarch1<<<512 * 16, 256>>>((const float *)b, (float *)(b + (512u << 20)), 128, 8); });
+            q[i] = 2.0 * 128 * (4u << 20) / m2 / 1e6;
+        }
+        printf("piece %2zu (after %5.1f GB): %6.0f GB/s   quarters %6.0f %6.0f %6.0f %6.0f\n", k, k * piece / 1e9, gbs, q[0], q[1], q[2], q[3]);
+        sc.push_back({gbs, (int)k});
+    }
+    std::sort(sc.begin(), sc.end());
+    auto run = [&](const char *name, const std::vector<int> &idx) {
+        for (int q = 0; q < 5; ++q) g.in[q] = (const float *)pc[idx[q]];
+        for (int q = 0; q < 4; ++q) g.out[q] = (float *)pc[idx[5 + q]];
+        printf("%-28s pieces", name);
+        for (int i : idx) printf(" %d", i);
+        printf(": ");
+        go<2, 2, 8, 1, true, false>(80, 32, 0);
+    };
+    const int m = (int)sc.size();
+    std::vector<int> fast, slow, spread, run9;
+    for (int i = 0; i < 9; ++i) { slow.push_back(sc[i].second); fast.push_back(sc[m - 1 - i].second); spread.push_back(i * (m - 1) / 8); run9.push_back(i); }
+    for (int rep = 0; rep < 2; ++rep) { run("nine fastest", fast); run("nine slowest", slow); run("spread over the device", spread); run("first nine (one arena)", run9); }
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && !strcmp(argv[1], "mixarena")) { hipEventCreate(&e0); hipEventCreate(&e1); return mixarena(); }
+    if (argc > 1 && !strcmp(argv[1], "skew")) { hipEventCreate(&e0); hipEventCreate(&e1); return skews(); }
+    if (argc > 2 && !strcmp(argv[1], "ballast")) { hipEventCreate(&e0); hipEventCreate(&e1); return ballast(atof(argv[2])); }
     hipEventCreate(&e0); hipEventCreate(&e1);
+    if (argc > 1 && !strcmp(argv[1], "place")) return placement(argc > 2 ? atoi(argv[2]) : 5);
     const int n = 1024, nz = 1024;
     g_vox = (size_t)n * n * nz;
     const size_t per = g_vox * 4 + 69888;
