@@ -239,11 +239,17 @@ int tomo_release_scratch(int device);
  * On MI355X the speed of the plane-marching TV kernels depends on where in HBM their arrays lie (PD_TV launch at 1024^3:
  * 10.1 ms with the arena in one block, 9.1-9.3 ms in another of the same process), so an arena of
  * >= 1 GiB is chosen among up to `tries` candidate allocations held at once, each scored by a ~7 ms z-march probe; the
- * rest are freed again.  Default 4 (environment TOMO_MI355X_PLACE_TRIES), 1 = plain hipMalloc.  Candidates are only
+ * rest are freed again.  Default 6 (environment TOMO_MI355X_PLACE_TRIES), 1 = plain hipMalloc.  Candidates are only
  * taken while the device keeps 4 GiB free.
  * tomo_placement_last reports the most recent search of this process: returns the number of candidates scored
  * (0 = none yet), *bytes the block size, *chosen the index kept, scores_GBps[i] the probe rate of candidate i. */
 int tomo_set_placement_tries(int tries);
+/* A placed scratch block for callers that keep their own plane-marching work arrays (the z-slab drivers hold ghosted
+ * copies of U, P1..3 and Input per rank; the reference's multi-GPU demo has cupy allocate them,
+ * Demos/methods_IR_legacy/MultiGPU_demo.py:144-190): `bytes` of device memory owned by the library, one block per
+ * (device, stream, slot 0..7), grow-only -- asking a slot for MORE than it holds frees the old block, so earlier pointers
+ * into it die --, released by tomo_release_scratch.  Placement as above. */
+int tomo_placed_scratch(int device, int slot, size_t bytes, void *stream, void **out_dev);
 int tomo_placement_last(size_t *bytes, int *chosen, double *scores_GBps, int capacity);
 
 /* Slab (multi-GPU) form of one PD-TV iteration on arrays that carry ghost planes:

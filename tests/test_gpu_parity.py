@@ -536,7 +536,7 @@ def test_scratch_arena_placement_search(oracle, ops):
                 assert all(500.0 < s < 8000.0 for s in rep["scores_GBps"]), rep      # a z-march over HBM
                 assert rep["scores_GBps"][rep["chosen"]] == max(rep["scores_GBps"])
     finally:
-        ops.set_placement_tries(4)
+        ops.set_placement_tries(6)
         _lib.check(L.tomo_release_scratch(0))
     assert np.array_equal(got[3], got[1])
     want = oracle.pd_tv(x[:14], 0.04, 6, 0, 1, 8.0, False)   # the oracle on a slab: 6 iterations reach 6 planes up, 8 of 14 are exact

@@ -161,3 +161,33 @@ def test_pdtv_thin_volumes_direct_abi():
             err = np.linalg.norm(g - want) / np.linalg.norm(want)
             assert err < 1e-6 and (variant != 22 or np.array_equal(g, want)), (variant, dz, err)
     ops.set_variant("pdtv", 0)
+
+
+def test_placed_work_arrays_are_disjoint_views_of_one_library_block():
+    """ops.placed_empty (the slab drivers' allocator): one tensor per spec inside one block the library owns and places,
+    256-byte aligned, ARRAY_SKEW apart, writable without touching each other; the same request returns the same block;
+    pd_tv_slab on such arrays returns a copy (the block is reused by the next call)."""
+    from tomobar_amd import ops
+    from tomobar_amd.slab import SlabComm, pd_tv_slab
+    dev = torch.device("cuda", 0)
+    specs = [((5, 33, 70), torch.float32)] * 3 + [((5, 33, 70), torch.float16)] * 2
+    a = ops.placed_empty(specs, dev, slot=3)
+    assert [tuple(t.shape) for t in a] == [s for s, _ in specs] and [t.dtype for t in a] == [d for _, d in specs]
+    spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in a)
+    for (b0, e0), (b1, e1) in zip(spans, spans[1:]):
+        assert b0 % 256 == 0 and b1 % 256 == 0 and b1 - e0 >= ops.ARRAY_SKEW
+    for i, t in enumerate(a):
+        t.fill_(i + 1)
+    torch.cuda.synchronize()
+    assert [float(t.float().min()) for t in a] == [float(t.float().max()) for t in a] == [1.0, 2.0, 3.0, 4.0, 5.0]
+    b = ops.placed_empty(specs, dev, slot=3)
+    assert [t.data_ptr() for t in b] == [t.data_ptr() for t in a]
+    # the driver's result must survive the next call on the same block
+    rng = np.random.default_rng(2)
+    v1 = torch.from_numpy(rng.random((9, 40, 70)).astype(np.float32)).cuda()
+    v2 = torch.from_numpy(rng.random((9, 40, 70)).astype(np.float32)).cuda()
+    comm = SlabComm(0, 1, dev)
+    r1 = pd_tv_slab(v1, comm, 0.04, 6, 0, 1, 8.0, False)
+    keep = r1.clone()
+    r2 = pd_tv_slab(v2, comm, 0.04, 6, 0, 1, 8.0, False)
+    assert torch.equal(r1, keep) and not torch.equal(r1, r2)

@@ -65,7 +65,7 @@ def test_placement_controls_are_host_state():
     for bad in (0, -1, 9, 100):
         assert L.tomo_set_placement_tries(bad) == _lib.E_INVALID, bad
         assert b"placement tries" in L.tomo_last_error()
-    for good in (1, 8, 4):
+    for good in (1, 8, 6):
         assert L.tomo_set_placement_tries(good) == _lib.OK
     nbytes, chosen, scores = C.c_size_t(7), C.c_int(7), (C.c_double * 8)()
     assert L.tomo_placement_last(C.byref(nbytes), C.byref(chosen), scores, 8) == 0

@@ -80,6 +80,7 @@ SIGNATURES = {
     "tomo_roftv_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "tomo_release_scratch": (_i, [_i]),
     "tomo_set_placement_tries": (_i, [_i]),
+    "tomo_placed_scratch": (_i, [_i, _i, _sz, _vp, C.POINTER(_vp)]),
     "tomo_placement_last": (_i, [C.POINTER(C.c_size_t), C.POINTER(_i), C.POINTER(C.c_double), _i]),
     "tomo_pdtv_iter_slab": (_i, [_i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i,
                                  _f, _f, _f, _f, _i, _i, _i, _vp]),

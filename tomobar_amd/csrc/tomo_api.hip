@@ -318,7 +318,7 @@ int placement_tries()
 {
     if (g_place_tries < 0) {
         const char *e = std::getenv("TOMO_MI355X_PLACE_TRIES");
-        const int v = e ? std::atoi(e) : 4;
+        const int v = e ? std::atoi(e) : 6;
         g_place_tries = v < 1 ? 1 : (v > PLACE_MAX_TRIES ? PLACE_MAX_TRIES : v);
     }
     return g_place_tries;
@@ -420,6 +420,13 @@ int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void 
     }
     *out = a.ptr;
     return TOMO_OK;
+}
+
+extern "C" int tomo_placed_scratch(int device, int slot, size_t bytes, void *stream, void **out_dev)
+{
+    TOMO_REQUIRE(device >= 0 && slot >= 0 && slot < 8 && bytes > 0 && out_dev != nullptr, "bad placed-scratch request (slot 0 .. 7)");
+    TOMO_ON_DEVICE(device);
+    return tomo_arena_get(device, as_stream(stream), ARENA_CALLER0 + slot, bytes, out_dev);
 }
 
 extern "C" int tomo_release_scratch(int device)

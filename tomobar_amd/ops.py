@@ -232,9 +232,39 @@ def get_variant(kernel: str) -> int:
     return getattr(_variant_state, "v", {}).get((L.flavour(), kernel), 0)
 
 
+class _DeviceBytes:
+    """Zero-copy hand-over of library-owned device memory to torch (``torch.as_tensor`` reads ``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+ARRAY_SKEW = 69888   # bytes between consecutive work arrays of a placed block (what the library uses between its own)
+
+
+def placed_empty(specs, device, slot: int = 0):
+    """Uninitialised work arrays inside ONE placed scratch block of the library (include/tomo_mi355x.h,
+    tomo_placed_scratch): ``specs`` is a list of (shape, dtype); returns one tensor per entry, 256-byte aligned and
+    ``ARRAY_SKEW`` apart.  The block belongs to the library (grow-only per (device, stream, slot), freed by
+    ``tomo_release_scratch``): the tensors are views for the duration of one driver call, not allocations to keep."""
+    device = torch.device(device)
+    sizes, total = [], 0
+    for shape, dtype in specs:
+        nb = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        sizes.append((total, nb))
+        total += (nb + 255) // 256 * 256 + ARRAY_SKEW
+    out = C.c_void_p(0)
+    with torch.cuda.device(device):
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        L.check(L.lib().tomo_placed_scratch(device.index or 0, int(slot), total, stream, C.byref(out)))
+        block = torch.as_tensor(_DeviceBytes(out.value, total), device=device)
+    return [block[o:o + nb].view(dtype).view(tuple(shape)) for (o, nb), (shape, dtype) in zip(sizes, specs)]
+
+
 def set_placement_tries(tries: int):
     """Candidate allocations the library scores when it places a scratch arena of >= 1 GiB (include/tomo_mi355x.h,
-    tomo_set_placement_tries; default 4 or TOMO_MI355X_PLACE_TRIES; 1 = plain hipMalloc)."""
+    tomo_set_placement_tries; default 6 or TOMO_MI355X_PLACE_TRIES; 1 = plain hipMalloc)."""
     L.check(L.lib().tomo_set_placement_tries(int(tries)))
 
 

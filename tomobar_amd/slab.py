@@ -319,7 +319,8 @@ class PdSlab:
     Arrays address ``[lo + nz_local + hi][dy][dx]`` with ``lo = GHOST`` below an interior boundary (else 0) and
     ``hi = GHOST`` above one (else 0); the first local plane is index ``lo``."""
 
-    def __init__(self, data: torch.Tensor, has_lo: bool, has_hi: bool, half: bool, pair_fn: Callable, step_fn: Callable):
+    def __init__(self, data: torch.Tensor, has_lo: bool, has_hi: bool, half: bool, pair_fn: Callable, step_fn: Callable,
+                 alloc: Optional[Callable] = None):
         nzl, dy, dx = data.shape
         if (has_lo or has_hi) and nzl < GHOST:
             raise ValueError(f"PD_TV slabs must hold at least {GHOST} slices")
@@ -333,13 +334,20 @@ class PdSlab:
         self.half = bool(half)
         # only the initial duals need zeros; every other plane that influences an output is copied, received or
         # overwritten before it is read (the outermost Input ghost only feeds warm-up values that are discarded)
-        self.inp = torch.empty((planes, dy, dx), dtype=torch.float32, device=dev)
+        # `alloc(specs, device)` (the HIP drivers pass ops.placed_empty): the nine work arrays as views of one block the
+        # library places in HBM ("placement"); default: nine allocations of the caller's allocator
+        shape = (planes, dy, dx)
+        specs = [(shape, torch.float32)] * 3 + [(shape, pd)] * 6
+        arrs = alloc(specs, dev) if alloc is not None else [torch.empty(sh, dtype=dt, device=dev) for sh, dt in specs]
+        self.placed = alloc is not None   # the arrays belong to the library's block: results leave it as copies
+        self.inp = arrs[0]
         self.inp[self.lo:self.lo + nzl] = data
         # the first step reads its primal variable from ``inp`` (U^0 = Input), so U[0] needs no initial copy
-        self.U = [torch.empty((planes, dy, dx), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.U = arrs[1:3]
         self.first = True
-        self.P = [[torch.zeros((planes, dy, dx), dtype=pd, device=dev) for _ in range(3)],
-                  [torch.empty((planes, dy, dx), dtype=pd, device=dev) for _ in range(3)]]
+        self.P = [arrs[3:6], arrs[6:9]]
+        for t in self.P[0]:
+            t.zero_()
         self.pair_fn, self.step_fn = pair_fn, step_fn
         self.cur = 0  # buffer set holding the current iterate
 
@@ -436,6 +444,11 @@ class PdSlab:
         return [self.inp[h:h + GHOST]] if self.has_hi else []
 
 
+def _hip_alloc(specs, device):
+    from . import ops
+    return ops.placed_empty(specs, device, slot=0)
+
+
 def _ptr3(ts):
     return (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
 
@@ -472,7 +485,8 @@ def pd_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, m
     theta = np.float32(1.0)
     lt = np.float32(tau / regularisation_parameter)
     comm.validate_slabs(data.shape[0], GHOST)
-    st = PdSlab(data, comm.has_lo, comm.has_hi, half_precision, pair_fn or _hip_pd_pair, step_fn or _hip_pd_step)
+    st = PdSlab(data, comm.has_lo, comm.has_hi, half_precision, pair_fn or _hip_pd_pair, step_fn or _hip_pd_step,
+                alloc=_hip_alloc if (pair_fn is None and step_fn is None and data.is_cuda) else None)
     comm.exchange(st.initial_send_down(), st.initial_recv_down(), st.initial_send_up(), st.initial_recv_up())
     edge_ranges, interior = st.boundary_ranges()
     # Overlap: the planes the neighbours wait for are computed first (two thin launches), their exchange runs on RCCL's
@@ -503,7 +517,7 @@ def pd_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, m
     if out is not None:
         out.copy_(res)
         return out
-    return res
+    return res.clone() if (st.placed and iterations > 0) else res
 
 
 # ------------------------------------------------------------------------------------------------ ROF_TV on a slab
@@ -511,7 +525,8 @@ class RofSlab:
     """Ghosted ping-pong state for ROF_TV: two ghost planes of U below (D3 of the plane below needs U two planes
     down), one above."""
 
-    def __init__(self, data: torch.Tensor, has_lo: bool, has_hi: bool, half: bool, step_fn: Callable):
+    def __init__(self, data: torch.Tensor, has_lo: bool, has_hi: bool, half: bool, step_fn: Callable,
+                 alloc: Optional[Callable] = None):
         nzl, dy, dx = data.shape
         self.nzl, self.dy, self.dx = nzl, dy, dx
         self.lo = 2 if has_lo else 0
@@ -519,9 +534,11 @@ class RofSlab:
         planes = nzl + self.lo + self.hi
         dev = data.device
         self.half = bool(half)
-        self.inp = torch.empty((planes, dy, dx), dtype=torch.float32, device=dev)
+        specs = [((planes, dy, dx), torch.float32)] * 3
+        arrs = alloc(specs, dev) if alloc is not None else [torch.empty(sh, dtype=dt, device=dev) for sh, dt in specs]
+        self.inp = arrs[0]
         self.inp[self.lo:self.lo + nzl] = data
-        self.U = [torch.empty((planes, dy, dx), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.U = arrs[1:3]
         self.U[0][self.lo:self.lo + nzl] = data
         self.step_fn = step_fn
 
@@ -570,7 +587,8 @@ def _hip_rof_step(inp, u_in, u_out, dx, dy, nzl, lo, hi, lam, tau, half, zr=None
 def rof_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, time_marching_parameter,
                 half_precision=False, step_fn: Optional[Callable] = None, out=None, overlap: bool = True):
     comm.validate_slabs(data.shape[0])
-    st = RofSlab(data, comm.has_lo, comm.has_hi, half_precision, step_fn or _hip_rof_step)
+    st = RofSlab(data, comm.has_lo, comm.has_hi, half_precision, step_fn or _hip_rof_step,
+                 alloc=_hip_alloc if (step_fn is None and data.is_cuda) else None)
     lam, tau = np.float32(regularisation_parameter), np.float32(time_marching_parameter)
     comm.exchange(st.send_down(0), st.recv_down(0), st.send_up(0), st.recv_up(0))
     edge_ranges, interior = st.boundary_ranges()
