@@ -428,8 +428,114 @@ static int mixarena()
     return 0;
 }
 
+// "vmm G_MB": the arena built from physical chunks of G MB (hipMemCreate) mapped into one reserved address range, in
+// allocation order and in a shuffled order: does the large-scale physical layout of the block decide the speed?
+static int vmm(size_t g_mb, int narena)
+{
+    const int n = 1024, nz = 1024;
+    g_vox = (size_t)n * n * nz;
+    g.n = n; g.nz = nz;
+    const size_t per = g_vox * 4 + 69888;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess) { printf("no VMM\n"); return 1; }
+    const size_t G = (g_mb << 20) / gran * gran;
+    const size_t total = (per * 9 + G - 1) / G * G;
+    const size_t nch = total / G;
+    printf("granularity %zu KB, chunk %zu MB, %zu chunks per arena\n", gran >> 10, G >> 20, nch);
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    auto run = [&](const char *name, char *b) {
+        for (int q = 0; q < 5; ++q) g.in[q] = (const float *)(b + per * q);
+        for (int q = 0; q < 4; ++q) g.out[q] = (float *)(b + per * (5 + q));
+        printf("%-36s: ", name);
+        go<2, 2, 8, 1, true, false>(80, 32, 0);
+    };
+    for (int k = 0; k < narena; ++k) {
+        std::vector<hipMemGenericAllocationHandle_t> h(nch);
+        for (size_t i = 0; i < nch; ++i)
+            if (hipMemCreate(&h[i], G, &prop, 0) != hipSuccess) { printf("hipMemCreate failed at chunk %zu\n", i); return 1; }
+        for (int mode = 0; mode < 3; ++mode) {
+            void *va = nullptr;
+            if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess) { printf("reserve failed\n"); return 1; }
+            std::vector<size_t> order(nch);
+            for (size_t i = 0; i < nch; ++i) order[i] = i;
+            if (mode == 1) { unsigned r = 12345u + k; for (size_t i = nch - 1; i > 0; --i) { r = r * 1664525u + 1013904223u; std::swap(order[i], order[(r >> 8) % (i + 1)]); } }
+            if (mode == 2) { const size_t st = 9; std::vector<size_t> o2; for (size_t a = 0; a < st; ++a) for (size_t i = a; i < nch; i += st) o2.push_back(i); order = o2; }  // stride 9: neighbours in VA are far apart physically
+            for (size_t i = 0; i < nch; ++i)
+                if (hipMemMap((char *)va + i * G, G, 0, h[order[i]], 0) != hipSuccess) { printf("map failed\n"); return 1; }
+            if (hipMemSetAccess(va, total, &acc, 1) != hipSuccess) { printf("access failed\n"); return 1; }
+            hipMemset(va, 0, per * 9);
+            char nm[64]; snprintf(nm, sizeof nm, "arena %d, chunks %s", k, mode == 0 ? "in order" : mode == 1 ? "shuffled" : "stride 9");
+            run(nm, (char *)va);
+            run(nm, (char *)va);
+            hipDeviceSynchronize();
+            hipMemUnmap(va, total);
+            hipMemAddressFree(va, total);
+        }
+        // keep the handles: the next arena takes the next physical memory
+    }
+    return 0;
+}
+
+// "vmmcmp": inside ONE process, arenas built from 2 / 64 / 1024 MB chunks and a plain hipMalloc arena, alternately, all
+// held until the end (so every arena has its own physical memory): chunk size or position?
+static int vmmcmp()
+{
+    const int n = 1024, nz = 1024;
+    g_vox = (size_t)n * n * nz;
+    g.n = n; g.nz = nz;
+    const size_t per = g_vox * 4 + 69888;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    auto run = [&](const char *name, char *b) {
+        for (int q = 0; q < 5; ++q) g.in[q] = (const float *)(b + per * q);
+        for (int q = 0; q < 4; ++q) g.out[q] = (float *)(b + per * (5 + q));
+        printf("%-36s: ", name);
+        go<2, 2, 8, 1, true, false>(80, 32, 0);
+    };
+    const size_t gs[] = {64, 0, 2, 1024, 64, 0, 2};
+    int k = 0;
+    for (size_t g_mb : gs) {
+        char nm[64];
+        size_t fr, tot; hipMemGetInfo(&fr, &tot);
+        if (fr < per * 9 + (size_t)8e9) break;
+        if (g_mb == 0) {
+            char *b; if (hipMalloc(&b, per * 9 + 4096) != hipSuccess) break;
+            hipMemset(b, 0, per * 9);
+            snprintf(nm, sizeof nm, "arena %d: hipMalloc", k++);
+            run(nm, b);
+            continue;
+        }
+        const size_t G = g_mb << 20, total = (per * 9 + G - 1) / G * G, nch = total / G;
+        void *va = nullptr;
+        if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess) { printf("reserve failed\n"); return 1; }
+        for (size_t i = 0; i < nch; ++i) {
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, G, &prop, 0) != hipSuccess) { printf("create failed\n"); return 1; }
+            if (hipMemMap((char *)va + i * G, G, 0, h, 0) != hipSuccess) { printf("map failed\n"); return 1; }
+        }
+        hipMemSetAccess(va, total, &acc, 1);
+        hipMemset(va, 0, per * 9);
+        snprintf(nm, sizeof nm, "arena %d: %zu MB chunks", k++, g_mb);
+        run(nm, (char *)va);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "vmmcmp")) { hipEventCreate(&e0); hipEventCreate(&e1); return vmmcmp(); }
+    if (argc > 2 && !strcmp(argv[1], "vmm")) { hipEventCreate(&e0); hipEventCreate(&e1); return vmm((size_t)atol(argv[2]), argc > 3 ? atoi(argv[3]) : 5); }
     if (argc > 1 && !strcmp(argv[1], "mixarena")) { hipEventCreate(&e0); hipEventCreate(&e1); return mixarena(); }
     if (argc > 1 && !strcmp(argv[1], "skew")) { hipEventCreate(&e0); hipEventCreate(&e1); return skews(); }
     if (argc > 2 && !strcmp(argv[1], "ballast")) { hipEventCreate(&e0); hipEventCreate(&e1); return ballast(atof(argv[2])); }
