@@ -445,7 +445,8 @@ def measure(args, env):
             per_prox = 0
             flags = world == 1   # the whole-volume driver tells a three-iteration launch when the duals are zero / unused
             for i, k in enumerate(plan):
-                rd = 4 + 4 + (0 if (flags and i == 0 and k == 3) else 3 * pb)          # U, Input, P1..3
+                first = flags and i == 0 and k == 3   # U IS Input then (one array), and the duals are zero (not read)
+                rd = (4 if first else 4 + 4 + 3 * pb)                                   # U, Input, P1..3
                 wr = 4 + (0 if (flags and i == len(plan) - 1 and k == 3) else 3 * pb)  # U, P1..3
                 per_prox += (rd + wr) * V
             comp_total["pdtv"] = per_prox * sub_its

@@ -46,7 +46,7 @@ constexpr int xk_p_base(int K, int RY, int s) { return s <= 1 ? 0 : xk_p_base(K,
 constexpr int xk_in_rows(int K, int RY) { return RY + 2 * (K - 2); }
 constexpr int xk_lag_slots(int K, int RY) { return xk_p_base(K, RY, K) + K * xk_in_rows(K, RY); }
 
-template <typename T, bool NONNEG, bool ANISO, int FAST, int K, int RY, int WX, int WY, bool LAG = false, int LREG = 0>
+template <typename T, bool NONNEG, bool ANISO, int FAST, int K, int RY, int WX, int WY, bool LAG = false, int LREG = 0, bool FIRST = false>
 __global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(2))) void pd_zmarch_xk_kernel(PdArgs a, int gx, int gy, int tiles_per_xcd)
 {
     constexpr int NR = RY + 2 * K;
@@ -165,7 +165,12 @@ __global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
                 for (int i = 0; i < NR; ++i) U0n[i] = 0.0f;
             }
-            if constexpr (!EDGE) {
+            if constexpr (FIRST) {
+                // first launch of a prox as its own instantiation: the duals are zero and Input IS the iterate -- no dual
+                // is requested, and Input(t) below is the plane of U this lane already holds (26 requests per step, not 65)
+#pragma unroll
+                for (int i = 0; i < NR; ++i) { Pw[0][i] = 0.0f; Pw[1][i] = 0.0f; Pw[2][i] = 0.0f; }
+            } else if constexpr (!EDGE) {
                 // short form: no test.  On the first launch of a prox (duals are zero, nothing to read) the descriptor has
                 // zero records: the range check answers every load with 0 and no request leaves the CU.
                 // Requests go out row by row (U of the next plane was requested above, in row order, too): loads return in
@@ -188,9 +193,14 @@ __global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(2)
                     for (int i = 0; i < NR - 1; ++i) Pw[c][i] = io.ldd(pp, xo, rowoff(i, ec));
                 }
             }
-            const float *ip = a.in + sz * ((a.probe & 4) ? 0 : t);
+            if constexpr (FIRST) {
 #pragma unroll
-            for (int i = 1; i < NR - 1; ++i) In[0][i] = io.ldf(ip, xo, rowoff(i, ec));
+                for (int i = 1; i < NR - 1; ++i) In[0][i] = U0c[i];
+            } else {
+                const float *ip = a.in + sz * ((a.probe & 4) ? 0 : t);
+#pragma unroll
+                for (int i = 1; i < NR - 1; ++i) In[0][i] = io.ldf(ip, xo, rowoff(i, ec));
+            }
             if (LAG) {  // Input(t) for the later stages: ring slot t mod K
                 const int q = t % K;
 #pragma unroll
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(64 * WX * WY) __attribute__((amdgpu_waves_per_eu(2)
     }
 }
 
-template <typename T, bool NONNEG, bool ANISO, int FAST, int K, int RY, int WX, int WY, bool LAG = false, int LREG = 0>
+template <typename T, bool NONNEG, bool ANISO, int FAST, int K, int RY, int WX, int WY, bool LAG = false, int LREG = 0, bool FIRST = false>
 static int pd_zmarch_xk_launch(PdArgs a, hipStream_t st, long want_per_simd = 32, int min_chunk = 24)
 {
     const int nout = a.out_end - a.out_begin;
@@ -437,10 +447,10 @@ static int pd_zmarch_xk_launch(PdArgs a, hipStream_t st, long want_per_simd = 32
     // LDS on a prefetch buffer would have to live with
     if (a.probe & 8) {
         dyn = 72 * 1024;
-        (void)hipFuncSetAttribute((const void *)pd_zmarch_xk_kernel<T, NONNEG, ANISO, FAST, K, RY, WX, WY, LAG, LREG>,
+        (void)hipFuncSetAttribute((const void *)pd_zmarch_xk_kernel<T, NONNEG, ANISO, FAST, K, RY, WX, WY, LAG, LREG, FIRST>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     }
 #endif
-    pd_zmarch_xk_kernel<T, NONNEG, ANISO, FAST, K, RY, WX, WY, LAG, LREG><<<(unsigned)blocks, 64 * WX * WY, dyn, st>>>(a, gx, gy, tiles_per_xcd);
+    pd_zmarch_xk_kernel<T, NONNEG, ANISO, FAST, K, RY, WX, WY, LAG, LREG, FIRST><<<(unsigned)blocks, 64 * WX * WY, dyn, st>>>(a, gx, gy, tiles_per_xcd);
     return TOMO_OK;
 }

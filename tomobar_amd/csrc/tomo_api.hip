@@ -284,8 +284,8 @@ static std::map<arena_key, arena_t> g_arenas;
 // not see the difference (6.1-6.3 TB/s everywhere), a z-march over one array of 4 MB planes does (4.9 vs 5.3 TB/s per 8.6 GB
 // chunk, two levels, roughly a quarter of the device in the slow one and a different quarter in every process).  So a block
 // of >= 1 GiB is chosen among up to `tries` candidate allocations held at the same time: each is scored with a z-march
-// probe over the whole block (~7 ms per 34 GB), the search stops at the first candidate that beats an earlier one by 5 %
-// (two levels: that one is in the fast class), the best is kept and the others are freed.  TOMO_MI355X_PLACE_TRIES=1 (or
+// probe over the whole block (~7 ms per 34 GB), the search stops at the first candidate that beats an earlier one by 8 %
+// (blocks score 4.87, 5.12 or 5.29 TB/s -- the launch then takes 10.1, 9.5 or 9.2 ms --: that one is in the fast class), the best is kept and the others are freed.  TOMO_MI355X_PLACE_TRIES=1 (or
 // tomo_set_placement_tries(1)) turns the search off; candidates are only taken while the device has room for them.
 namespace {
 // one array of planes of 1024 x 1024 floats: a workgroup (2 x 2 waves) owns 128 columns x 16 rows (+3 halo rows either side)
@@ -376,7 +376,7 @@ int placed_malloc(hipStream_t st, size_t bytes, void **out)
         rec.tries = t + 1;
         if (rec.chosen < 0 || rec.score[t] > rec.score[rec.chosen]) rec.chosen = t;
         lo = (t == 0) ? rec.score[t] : std::min(lo, rec.score[t]);
-        if (t >= 1 && rec.score[rec.chosen] >= 1.05 * lo) break;  // two levels: this one is in the fast class
+        if (t >= 1 && rec.score[rec.chosen] >= 1.08 * lo) break;  // levels 4.87 / 5.12 / 5.29 TB/s: this one is in the fast class
     }
     for (int t = 0; t < rec.tries; ++t)
         if (t != rec.chosen) (void)hipFree(cand[t]);

@@ -463,7 +463,9 @@ int pd_xk3_launch(const PdArgs &a, int variant, hipStream_t st)
         else return pd_zmarch_xk_launch<T, NN, AN, 0, 3, 4, 2, 2, true>(a, st);  // 4 rows per lane: the IEEE expansions need the registers
     }
 #endif
-    if (variant == 22 || pd_default_is_exact<T>()) return pd_zmarch_xk_launch<T, NN, AN, 2, 3, 8, 2, 2, true, 10>(a, st);
+    const bool first = a.p_in_zero && a.u_in == a.in;  // first launch of a prox: its own instantiation (see pd_zmarch_xk.inl, FIRST)
+    if (variant == 22 || pd_default_is_exact<T>())
+        return first ? pd_zmarch_xk_launch<T, NN, AN, 2, 3, 8, 2, 2, true, 10, true>(a, st) : pd_zmarch_xk_launch<T, NN, AN, 2, 3, 8, 2, 2, true, 10>(a, st);
     // relaxed float32: ONE instantiation per TV type serves both settings of `nonneg` -- the clip threshold is a kernel
     // argument (0 or -inf; "u < -inf" is never true, so the iterate passes through exactly as the code without the test
     // would leave it).  The separate no-clip instantiation of the isotropic kernel allocated 256 registers with 154 spilled
@@ -472,6 +474,8 @@ int pd_xk3_launch(const PdArgs &a, int variant, hipStream_t st)
     // builds keep their two instantiations: there the no-clip one is the faster by 3 %.
     PdArgs b = a;
     b.nn_thr = NN ? 0.0f : -__builtin_inff();
+    // the first launch of a prox (zero duals, Input = iterate) has its own instantiation: 14 + 32 requests per step, not 26 + 32
+    if (first) return pd_zmarch_xk_launch<T, true, AN, 1, 3, 8, 2, 2, true, 10, true>(b, st);
     return pd_zmarch_xk_launch<T, true, AN, 1, 3, 8, 2, 2, true, 10>(b, st);
 }
 

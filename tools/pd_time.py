@@ -24,3 +24,4 @@ for name, variant, half in cases:
         ts.append(e0.elapsed_time(e1) / 10)
     print(f"{name:24s} {min(ts):7.3f} ms per three-iteration launch (min of {REPS}), median {sorted(ts)[len(ts)//2]:7.3f}; {min(ts) * 1e6 / (NZ * N * N):6.3f} ns per voxel  [{NZ} x {N}^2]", flush=True)
 ops.set_variant("pdtv", 0)
+print("placement of the scratch arena:", ops.placement_last(), flush=True)

@@ -22,3 +22,4 @@ for variant in (0, 22):
                     ts.append(e0.elapsed_time(e1) / 10)
                 print(f"variant {variant:2d} half {int(half)} methodTV {methodTV} nonneg {nonneg}: {min(ts):7.3f} ms per three-iteration launch", flush=True)
 ops.set_variant("pdtv", 0)
+print("placement of the scratch arena:", ops.placement_last(), flush=True)
