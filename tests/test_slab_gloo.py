@@ -271,3 +271,51 @@ def test_launch_plan_follows_the_library_maximum():
     assert pd_launch_plan(4, False, kmax=3) == [2, 2]
     assert pd_launch_plan(5, True, kmax=2) == [2, 2, 1]
     assert pd_launch_plan(3, False, kmax=1) == [1, 1, 1]
+
+
+def test_slab_states_take_their_arrays_from_an_allocator_hook():
+    """PdSlab / RofSlab ask `alloc(specs, device)` for their work arrays when one is given (the HIP drivers pass
+    ops.placed_empty: views of ONE block the library places in HBM) and fall back to one allocation per array; initial
+    duals are zeroed either way, and results of a run on borrowed arrays leave as copies."""
+    from oracle import tomo_oracle as O
+    from tomobar_amd import slab
+    from tomobar_amd.slab import PdSlab, RofSlab, SlabComm, pd_tv_slab
+    calls = []
+
+    def alloc(specs, device):
+        sizes = [int(np.prod(sh)) * torch.empty((), dtype=dt).element_size() for sh, dt in specs]
+        block = torch.full((sum(sizes) + 64 * len(sizes),), 0xA5, dtype=torch.uint8)   # dirty memory, like a reused arena
+        calls.append((len(specs), block))
+        out, o = [], 0
+        for (sh, dt), nb in zip(specs, sizes):
+            out.append(block[o:o + nb].view(dt).view(tuple(sh)))
+            o += nb + 64
+        return out
+
+    rng = np.random.default_rng(3)
+    vol = (rng.random((9, 12, 20)) * 0.3).astype(np.float32)
+    data = torch.from_numpy(vol)
+    for half in (False, True):
+        st = PdSlab(data, True, True, half, O.pd_pair_slab, O.pd_step_slab, alloc=alloc)
+        n, block = calls[-1]
+        assert n == 9 and st.placed
+        lo, hi = block.data_ptr(), block.data_ptr() + block.numel()
+        arrs = [st.inp] + st.U + st.P[0] + st.P[1]
+        assert all(lo <= t.data_ptr() < hi for t in arrs)
+        assert all(float(t.abs().max()) == 0.0 for t in st.P[0])                       # initial duals
+        assert st.P[0][0].dtype == (torch.float16 if half else torch.float32)
+        assert np.array_equal(st.local(st.inp).numpy(), vol)
+    assert not PdSlab(data, False, False, False, O.pd_pair_slab, O.pd_step_slab).placed
+    rs = RofSlab(data, True, False, False, O.rof_step_slab, alloc=alloc)
+    assert calls[-1][0] == 3 and np.array_equal(rs.local(rs.U[0]).numpy(), vol)
+    # a whole-volume run (world 1) through the driver on borrowed arrays: bit-identical, and the result is not a view of them
+    keep = slab._hip_alloc
+    slab._hip_alloc = alloc
+    try:
+        st = PdSlab(data, False, False, False, O.pd_pair_slab, O.pd_step_slab, alloc=slab._hip_alloc)
+        assert st.placed
+    finally:
+        slab._hip_alloc = keep
+    comm = SlabComm(0, 1)
+    got = pd_tv_slab(data, comm, 0.04, 5, 0, 1, 8.0, False, pair_fn=O.pd_pair_slab, step_fn=O.pd_step_slab)
+    assert np.array_equal(got.numpy(), O.pd_tv(vol, 0.04, 5, 0, 1, 8.0, False))
