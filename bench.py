@@ -381,6 +381,12 @@ def measure(args, env):
         reg = {"method": args.reg, "regul_param": 5e-4, "iterations": args.inner,
                "time_marching_step": 1e-3, "half_precision": args.half}
 
+    if reg is not None and slab is None:
+        # set-up, like the context and the sinogram: the library allocates and PLACES its TV scratch arena now (a search
+        # over up to six candidate blocks, 0.1-4 s once per process; DESIGN.md section 4 "placement") instead of inside
+        # the first proximal step -- with --warmup 0 that step would be a timed one
+        _ops.reserve_tv_scratch((nz, n, n), device, args.reg, args.half)
+
     def run(iters):
         d = {"projection_data": sino, "data_axes_labels_order": ["detY", "angles", "detX"]}
         if args.ring > 0.0:

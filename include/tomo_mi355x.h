@@ -243,6 +243,10 @@ int tomo_release_scratch(int device);
  * taken while the device keeps 4 GiB free.
  * tomo_placement_last reports the most recent search of this process: returns the number of candidates scored
  * (0 = none yet), *bytes the block size, *chosen the index kept, scores_GBps[i] the probe rate of candidate i. */
+/* Allocate (and place) the operators' scratch arena of this (device, stream) ahead of the first call that needs it --
+ * e.g. tomo_pdtv_scratch_bytes(...) at set-up time, so that the placement search (0.1-4 s) is not part of the first
+ * iteration.  Grow-only like every arena: a later call that needs more re-allocates. */
+int tomo_reserve_scratch(int device, size_t bytes, void *stream);
 int tomo_set_placement_tries(int tries);
 /* A placed scratch block for callers that keep their own plane-marching work arrays (the z-slab drivers hold ghosted
  * copies of U, P1..3 and Input per rank; the reference's multi-GPU demo has cupy allocate them,

@@ -528,9 +528,14 @@ def test_scratch_arena_placement_search(oracle, ops):
         for tries in (3, 1):
             _lib.check(L.tomo_release_scratch(0))
             ops.set_placement_tries(tries)
+            if tries == 3:   # set-up time reservation: the search runs here, the first prox finds its arena in place
+                ops.reserve_tv_scratch(shape, xd.device, "PD_TV", False)
+                reserved = ops.placement_last()
+                assert reserved is not None
             got[tries] = host(PD_TV_cupy(xd, 0.04, 6, 0, 1, 8.0, 0, False))
             if tries == 3:
                 rep = ops.placement_last()
+                assert rep == reserved
                 assert rep is not None and rep["bytes"] == L.tomo_pdtv_scratch_bytes(shape[2], shape[1], shape[0], 3, 0)
                 assert 1 <= len(rep["scores_GBps"]) <= 3 and 0 <= rep["chosen"] < len(rep["scores_GBps"])
                 assert all(500.0 < s < 8000.0 for s in rep["scores_GBps"]), rep      # a z-march over HBM

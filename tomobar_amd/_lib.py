@@ -79,6 +79,7 @@ SIGNATURES = {
     "tomo_pdtv_scratch_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "tomo_roftv_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "tomo_release_scratch": (_i, [_i]),
+    "tomo_reserve_scratch": (_i, [_i, _sz, _vp]),
     "tomo_set_placement_tries": (_i, [_i]),
     "tomo_placed_scratch": (_i, [_i, _i, _sz, _vp, C.POINTER(_vp)]),
     "tomo_placement_last": (_i, [C.POINTER(C.c_size_t), C.POINTER(_i), C.POINTER(C.c_double), _i]),

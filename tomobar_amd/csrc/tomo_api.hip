@@ -422,6 +422,14 @@ int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void 
     return TOMO_OK;
 }
 
+extern "C" int tomo_reserve_scratch(int device, size_t bytes, void *stream)
+{
+    TOMO_REQUIRE(device >= 0 && bytes > 0, "bad scratch reservation");
+    TOMO_ON_DEVICE(device);
+    void *p = nullptr;
+    return tomo_arena_get(device, as_stream(stream), ARENA_MAIN, bytes, &p);
+}
+
 extern "C" int tomo_placed_scratch(int device, int slot, size_t bytes, void *stream, void **out_dev)
 {
     TOMO_REQUIRE(device >= 0 && slot >= 0 && slot < 8 && bytes > 0 && out_dev != nullptr, "bad placed-scratch request (slot 0 .. 7)");

@@ -262,6 +262,18 @@ def placed_empty(specs, device, slot: int = 0):
     return [block[o:o + nb].view(dtype).view(tuple(shape)) for (o, nb), (shape, dtype) in zip(sizes, specs)]
 
 
+def reserve_tv_scratch(shape, device, method: str = "PD_TV", half: bool = False):
+    """Allocate and place the library's TV scratch arena for volumes of `shape` on the current stream of `device` now
+    (set-up time) instead of inside the first proximal step (include/tomo_mi355x.h, tomo_reserve_scratch)."""
+    device = torch.device(device)
+    nd = len(shape)
+    dz, dy, dx = (1, *shape) if nd == 2 else shape
+    lib = L.lib()
+    nbytes = lib.tomo_pdtv_scratch_bytes(dx, dy, dz, nd, int(bool(half))) if method == "PD_TV" else lib.tomo_roftv_scratch_bytes(dx, dy, dz, nd)
+    with torch.cuda.device(device):
+        L.check(lib.tomo_reserve_scratch(device.index or 0, nbytes, C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+
+
 def set_placement_tries(tries: int):
     """Candidate allocations the library scores when it places a scratch arena of >= 1 GiB (include/tomo_mi355x.h,
     tomo_set_placement_tries; default 6 or TOMO_MI355X_PLACE_TRIES; 1 = plain hipMalloc)."""
