@@ -324,7 +324,7 @@ int placement_tries()
     return g_place_tries;
 }
 
-// GB/s of the probe over the block (min of two passes after a warm-up); 0 on any error
+// GB/s of the probe over the block (the better of two passes after a warm-up); 0 on any error
 double place_score(void *p, size_t bytes, hipStream_t st)
 {
     const int nz = (int)(bytes / 2 / ((size_t)4 << 20));
