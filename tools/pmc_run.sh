@@ -10,7 +10,7 @@ for what in "$@"; do
   i=0
   for pmc in "${GR[@]}"; do
     d=gpurun_out/pmc_${tag}/${what}_g${i}
-    rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $d -o p -- python tools/pmc_probe.py $what ${PMC_N:-1024} ${PMC_NZ:-1024} ${PMC_NA:-75} > $d.log 2>&1
+    timeout ${PMC_TIMEOUT:-300} rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $d -o p -- python tools/pmc_probe.py $what ${PMC_N:-1024} ${PMC_NZ:-1024} ${PMC_NA:-75} > $d.log 2>&1
     i=$((i+1))
   done
 done
