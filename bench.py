@@ -46,6 +46,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy ceiling)
 FP32_VALU_PEAK_TFLOPS = 157.3  # same guide: vector f32 peak (the issue roof of the 2-tap gathers in BP / FP)
 LDS_PEAK_BPS = 256.0 * 256 * 2.4e9  # same guide, LDS: ds_read_b128 256 B/clk/CU x 256 CUs x 2.4 GHz = 157 TB/s
+SUSTAINED_CLOCK_HZ = 2.03e9         # what the chip holds under the projector kernels (GRBM_GUI_ACTIVE / wall time,
+                                    # docs/kernels/bp.md): the LDS fractions are reported against both clocks
 
 # source files whose content decides the HBM traffic of each kernel class (profiles/pmc_traffic.json is only valid
 # for the sources it was measured on)
@@ -106,13 +108,20 @@ def parse():
     p.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"])
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     p.add_argument("--no-pmc", action="store_true",
-                   help="skip the live rocprofv3 --pmc passes that measure roofline.traffic (N = 1 only; ~1 minute)")
+                   help="never spawn the live rocprofv3 --pmc passes that measure roofline.traffic")
+    p.add_argument("--live-pmc", action="store_true",
+                   help="N = 1: measure roofline.traffic live with two child rocprofv3 --pmc passes (~25 s; each re-allocates the "
+                        "dominant kernel's arrays while this process keeps its own).  On by default for the default workload "
+                        "only, where it is known to fit; BENCH_LIVE_PMC=1 acts like the flag")
     p.add_argument("--cpu-slices", type=int, default=8)
     p.add_argument("--exact-tv", action="store_true",
                    help="PD_TV float32 duals with the reference's rounding sequence (tomo_set_variant('pdtv', 22): bit-identical "
                         "to the oracle, +5 ... +16 %% per launch; the default is within 1e-5); the workload string says so")
-    p.add_argument("--no-north-star", action="store_true",
-                   help="N > 1 only: skip the extra `north_star` block (strong scaling of configs[4] when it fits)")
+    p.add_argument("--north-star", action="store_true",
+                   help="N > 1 only: after the headline workload also run strong scaling of BASELINE configs[4] (when every "
+                        "rank's share fits) and report it as an extra `north_star` block; BENCH_NORTH_STAR=1 acts like the flag. "
+                        "Off by default: a second full workload multiplies the wall time of a driver that only varies --gpus")
+    p.add_argument("--no-north-star", action="store_true", help="accepted for compatibility (the block is opt-in now)")
     if len(sys.argv) == 1 and "TOMO_BENCH_ARGV" in os.environ and "RANK" in os.environ:  # rank started by self_launch()
         args = p.parse_args(json.loads(os.environ["TOMO_BENCH_ARGV"]))
     else:
@@ -125,6 +134,10 @@ def parse():
         args.config = os.environ["BENCH_CONFIG"]
     if os.environ.get("BENCH_STRONG", "0") not in ("", "0"):
         args.strong = True
+    if os.environ.get("BENCH_NORTH_STAR", "0") not in ("", "0") or os.environ.get("BENCH_NORTH_STAR_TEST", "0") not in ("", "0"):
+        args.north_star = True
+    if os.environ.get("BENCH_LIVE_PMC", "0") not in ("", "0"):
+        args.live_pmc = True
     apply_preset(args)
     return args
 
@@ -274,8 +287,9 @@ def live_traffic(dom, args, n, nz, sub):
         return None, "rocprofv3 not on PATH"
     if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
         return None, "this process already runs under a profiler: no nested counter passes"
+    quad = args.ring <= 0.0   # the drivers hand the residual over quad-interleaved unless a ring term reads it
     what = {"pdtv": ("pdtv22" if getattr(args, "exact_tv", False) else "pdtv0") + ("h" if args.half else ""),
-            "roftv": "roftv", "bp": "bp0", "fp": "fp"}[dom]
+            "roftv": "roftv", "bp": "bpq" if quad else "bp0", "fp": "fpq" if quad else "fp"}[dom]
     key = {"pdtv": ["xk_kernel"], "roftv": ["rof_"], "bp": ["bp_brick"], "fp": ["fp_tiled", "transpose"]}[dom]
     try:
         tmp = tempfile.mkdtemp(prefix="tomo_pmc_", dir="/tmp")
@@ -288,7 +302,7 @@ def live_traffic(dom, args, n, nz, sub):
             d = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py"), what, str(n), str(nz), str(sub)]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
@@ -383,8 +397,8 @@ def measure(args, env):
 
     if reg is not None and slab is None:
         # set-up, like the context and the sinogram: the library allocates and PLACES its TV scratch arena now (a search
-        # over up to six candidate blocks, 0.1-4 s once per process; DESIGN.md section 4 "placement") instead of inside
-        # the first proximal step -- with --warmup 0 that step would be a timed one
+        # over up to eight candidate blocks, 0.1-4 s once per process; docs/kernels/placement.md).  RecToolsIRCuPy does the
+        # same at the start of its first call; done here explicitly so that --warmup 0 does not time it
         _ops.reserve_tv_scratch((nz, n, n), device, args.reg, args.half)
 
     def run(iters):
@@ -475,29 +489,39 @@ def measure(args, env):
                     tf = 4.0 * upd / avg / 1e9
                     kernels[k]["valu_TFLOPs"] = tf
                     kernels[k]["frac_valu"] = tf / FP32_VALU_PEAK_TFLOPS
-                    kernels[k]["lds_floor_ms"] = upd * 8.0 / LDS_PEAK_BPS * 1e3
+                    kernels[k]["updates_per_s"] = upd / avg * 1e3
+                    kernels[k]["lds_floor_ms"] = upd * 8.0 / LDS_PEAK_BPS * 1e3           # at the 2.4 GHz spec clock
                     kernels[k]["frac_lds"] = kernels[k]["lds_floor_ms"] / avg
+                    kernels[k]["lds_floor_ms_sustained"] = kernels[k]["lds_floor_ms"] * 2.4e9 / SUSTAINED_CLOCK_HZ
+                    kernels[k]["frac_lds_sustained"] = kernels[k]["lds_floor_ms_sustained"] / avg
         dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
         # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/pmc_run.sh;
         # counters cannot be collected from inside this process).  It is reported only when the kernel sources are
         # byte-identical to the ones the counters were taken on and the configuration matches.
-        traffic, traffic_src = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            key = "pdtv_half" if (dom == "pdtv" and args.half) else dom
-            if key in pmc and (n, nz, na, args.os) == (1024, 1024, 900, 12):
-                ent = pmc[key]
-                cur = source_hash(dom)
-                traffic_src = {"measured_on_sources": ent.get("sources_sha16"), "current_sources": cur,
-                               "profile": ent.get("profile")}
-                if ent.get("sources_sha16") == cur:
-                    traffic = ent["traffic_bytes"]
-        except (OSError, ValueError):
-            pass
-        # ... and, on one GPU, measured live by this very run (unless --no-pmc): the committed figure stays in the line as
-        # `traffic_committed` for comparison
+        default_shape = (n, nz, na, args.os) == (1024, 1024, 900, 12)
+
+        def committed_traffic(kern):
+            """(bytes per launch, provenance) from profiles/pmc_traffic.json -- only for the shape it was measured on and only
+            while the kernel sources still hash to what the counters were taken on (tests/test_host_logic.py keeps the file
+            in step with HEAD)."""
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            except (OSError, ValueError):
+                return None, None
+            key = "pdtv_half" if (kern == "pdtv" and args.half) else kern
+            if key not in pmc or not default_shape or args.ring > 0.0 or getattr(args, "exact_tv", False):
+                return None, None
+            ent, cur = pmc[key], source_hash(kern)
+            src = {"measured_on_sources": ent.get("sources_sha16"), "current_sources": cur, "profile": ent.get("profile")}
+            return (ent["traffic_bytes"] if ent.get("sources_sha16") == cur else None), src
+
+        traffic, traffic_src = committed_traffic(dom)
+        # ... and measured live by this very run, as the cross-check of the committed figure (`traffic_committed` stays in
+        # the line): two child rocprofv3 --pmc passes, by default only for the default workload on one GPU, where they are
+        # known to fit beside this process (~25 s); elsewhere on request (--live-pmc); never with --no-pmc
         traffic_committed = traffic
-        if world == 1 and not getattr(args, "no_pmc", False):
+        want_live = world == 1 and not args.no_pmc and (args.live_pmc or (default_shape and not args.overridden))
+        if want_live:
             torch.cuda.empty_cache()
             live, how = live_traffic(dom, args, n, nz, sub)
             if live is not None:
@@ -517,6 +541,20 @@ def measure(args, env):
         if traffic is not None:
             roof["traffic_GBps"] = traffic / kernels[dom]["avg_ms"] / 1e6
             roof["frac_traffic"] = roof["traffic_GBps"] / HBM_PEAK_GBS
+        # BASELINE's metric names the back projector ("achieved HBM GB/s (backproj)"): its figures at the top level, whatever
+        # kernel dominates the step.  `achieved` = SURVEY 8d's algorithmic bytes 4 (S_s + V) per call / the measured call; the
+        # kernel is bound by LDS / VALU issue, not by HBM (docs/kernels/bp.md), so the LDS fractions ride along.
+        roof_bp = None
+        if "bp" in kernels:
+            kb = kernels["bp"]
+            bp_tr, bp_src = committed_traffic("bp")
+            roof_bp = {"bound": "hbm", "kernel": "bp", "achieved": kb["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": kb["frac_hbm"], "traffic": bp_tr, "traffic_source": bp_src,
+                       "avg_launch_ms": kb["avg_ms"], "launches": kb["launches"],
+                       "bytes_per_launch": kb["compulsory_bytes_per_launch"], "updates_per_s": kb["updates_per_s"],
+                       "frac_lds_spec_2.4GHz": kb["frac_lds"], "frac_lds_sustained_2.03GHz": kb["frac_lds_sustained"],
+                       "note": "north-star kernel; an LDS-gather kernel: 8 B of ds_read_b128 per voxel-angle update put its floor at "
+                               "lds_floor_ms, 4-5x above its HBM time (docs/kernels/bp.md)"}
         units = args.steps if args.strong else args.steps * world
         what = (f"{nz_total} slices of {n}^2 split over {world} z-slab(s)" if args.strong
                 else f"{nz} slices of {n}^2 per GPU; slab-iterations/s over {world} z-slab(s)")
@@ -539,9 +577,13 @@ def measure(args, env):
                        **({"backend_note": backend_note} if backend_note else {})},
             "roofline": roof, "kernels": kernels,
         }
+        if roof_bp is not None:
+            line["roofline_bp"] = roof_bp
         if halo is not None:
             line["halo"] = halo
-        placed = _ops.placement_last()   # where the library put its largest scratch arena ("placement")
+        # where the library put its TV scratch arena (docs/kernels/placement.md); "fast": False explains a PD_TV launch
+        # that is 4-10 % slower than the same sources on a block of the fast class
+        placed = _ops.placement_last()
         if placed is not None:
             line["placement"] = placed
         return line, sino, lc
@@ -626,38 +668,50 @@ def main():
     del sino
     # N > 1: the headline value above is what the contract asks for (weak scaling of the default workload unless flags /
     # BENCH_CONFIG say otherwise).  The north-star target is STRONG scaling of BASELINE configs[4] (2560^2 x 2160, 1800
-    # angles, OS 12, PD_TV + ring term): a driver that only varies --gpus never asks for it, so it is measured here as a
-    # second, clearly separate block whenever every rank's share fits its GPU (it does from 4 GPUs on).
+    # angles, OS 12, PD_TV + ring term): on request (--north-star / BENCH_NORTH_STAR=1) it is measured as a second, clearly
+    # separate block when every rank's share fits its GPU (it does from 4 GPUs on).  The block can only ADD to the line:
+    # the headline is persisted on stderr before the block starts, every rank proves it can allocate its share before any
+    # collective of the second workload is entered, and the ranks agree on that with one MIN-all-reduce.
     ns_test = os.environ.get("BENCH_NORTH_STAR_TEST", "0") not in ("", "0")  # dry run of this block on a shared GPU, tiny shape
-    if world > 1 and not args.no_north_star and (ns_test or not oversubscribed) and not (args.strong and args.config == "cfg5"):
+    if world > 1 and args.north_star and (ns_test or not oversubscribed) and not (args.strong and args.config == "cfg5"):
         import copy
+        if rank == 0:
+            print("[bench] headline (kept whatever the north-star block does): " + json.dumps(line), file=sys.stderr, flush=True)
         block = {"workload": "BASELINE configs[4], --strong"}
-        try:
-            ns = copy.copy(args)
-            for k in ("n", "nz", "angles", "os", "inner", "reg", "method", "ring"):
-                setattr(ns, k, None)
-            ns.config, ns.strong, ns.half, ns.steps, ns.warmup = "cfg5", True, False, 2, 1
-            if ns_test:
-                ns.n, ns.nz, ns.angles, ns.inner = 192, 12 * world, 96, 6
-            apply_preset(ns)
-            from tomobar_amd.slab import slab_bounds
-            share = max(slab_bounds(ns.nz, world, r)[1] - slab_bounds(ns.nz, world, r)[0] for r in range(world))
-            need = footprint_bytes(ns, share)
-            total_b = torch.cuda.mem_get_info(device)[1]
-            fits = torch.tensor([1 if need < 0.9 * total_b else 0], dtype=torch.int32)
-            dist.all_reduce(fits, op=dist.ReduceOp.MIN)
-            block.update({"per_gpu_slices": share, "estimated_bytes_per_gpu": need})
-            if int(fits.item()) == 1:
+        ns = copy.copy(args)
+        for k in ("n", "nz", "angles", "os", "inner", "reg", "method", "ring"):
+            setattr(ns, k, None)
+        ns.config, ns.strong, ns.half, ns.steps, ns.warmup = "cfg5", True, False, 2, 1
+        if ns_test:
+            ns.n, ns.nz, ns.angles, ns.inner = 192, 12 * world, 96, 6
+        apply_preset(ns)
+        from tomobar_amd.slab import slab_bounds
+        share = max(slab_bounds(ns.nz, world, r)[1] - slab_bounds(ns.nz, world, r)[0] for r in range(world))
+        need = footprint_bytes(ns, share)
+        total_b = torch.cuda.mem_get_info(device)[1]
+        ok = 1 if need < 0.9 * total_b else 0
+        if ok:   # prove it: one allocation of the estimated footprint, freed again (an OOM here strands nobody)
+            try:
                 torch.cuda.empty_cache()
                 _lib_release(device)
+                probe = torch.empty(int(need), dtype=torch.uint8, device=device)
+                del probe
+                torch.cuda.empty_cache()
+            except Exception:  # noqa: BLE001
+                ok = 0
+        fits = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(fits, op=dist.ReduceOp.MIN)
+        block.update({"per_gpu_slices": share, "estimated_bytes_per_gpu": need})
+        if int(fits.item()) == 1:
+            try:
                 ns_line, _, _ = measure(ns, env)
                 if rank == 0:
                     block.update({k: ns_line[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "scaling",
-                                                          "config", "roofline", "halo") if k in ns_line})
-            else:
-                block["skipped"] = f"a {share}-slice slab needs ~{need / 1e9:.0f} GB of the GPU's {total_b / 1e9:.0f} GB"
-        except Exception as e:  # noqa: BLE001 -- the headline line above must survive whatever happens in the extra block
-            block["error"] = repr(e)[:300]
+                                                          "config", "roofline", "roofline_bp", "halo") if k in ns_line})
+            except Exception as e:  # noqa: BLE001 -- reported in the block; the headline is already on stderr
+                block["error"] = repr(e)[:300]
+        else:
+            block["skipped"] = f"a {share}-slice slab needs ~{need / 1e9:.0f} GB of the GPU's {total_b / 1e9:.0f} GB (or could not be allocated on some rank)"
         if rank == 0:
             line["north_star"] = block
     if rank == 0:

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* raised whenever an entry point is added or a signature changes (tomobar_amd/_lib.py checks it at load) */
-#define TOMO_ABI_VERSION 4
+#define TOMO_ABI_VERSION 5
 
 enum {
     TOMO_OK = 0,
@@ -162,6 +162,24 @@ int tomo_bp3d_admm(tomo_ctx *ctx, int subset, const float *res_dev, float *z_dev
                    const float *u_dev, float *zu_out_dev, float tau, float rho, int relax_on,
                    float one_minus_alpha, float alpha, int nonneg, void *stream);
 
+/* Private layout of the residual BETWEEN tomo_fp3d_residual and its consumer tomo_bp3d_fista / _fista_momentum / _admm on
+ * the same context (round 5).  The reference materialises the residual as a [detY, angles, detX] CuPy array between
+ * grad_data_term's forward and back projection (data_fidelities.py:28-40); nobody else reads it on the plain LS / PWLS /
+ * KL path, so producer and consumer may agree on the layout the back projector stages fastest:
+ *   TOMO_RESIDUAL_PLANAR (default): res_dev is [nz][subset_size][nu], what every entry point documents.
+ *   TOMO_RESIDUAL_ZQUAD           : res_dev is [ceil(nz/4)][subset_size][nu][4] -- the four slices of a quad interleaved
+ *       (slices >= nz read as 0).  The forward projector's workgroup holds exactly these four values per (angle, pixel)
+ *       and stores them as ONE 16-byte word; the back projector stages one 16-byte load per (angle, quad, sample) where
+ *       the planar layout costs four dword gathers from rows nz * subset_size * nu floats apart.  Same arithmetic, bit
+ *       for bit.  res_dev must be 16-byte aligned and hold tomo_ctx_residual_elems(ctx, subset) floats.
+ * Only the three fused epilogue entry points and tomo_fp3d_residual follow the context's setting; tomo_fp3d / tomo_bp3d
+ * always take the planar layout, and tomo_fp3d_residual_ring (whose residual is read by tomo_ring_gh_reduce) refuses to
+ * run while ZQUAD is set. */
+enum { TOMO_RESIDUAL_PLANAR = 0, TOMO_RESIDUAL_ZQUAD = 1 };
+int tomo_ctx_set_residual_layout(tomo_ctx *ctx, int layout);
+int tomo_ctx_residual_layout(const tomo_ctx *ctx);
+size_t tomo_ctx_residual_elems(const tomo_ctx *ctx, int subset);
+
 /* ---------------------------------------------------------------- element-wise glue
  * tomo_momentum : x_t = x + beta*(x - x_old)                         methodsIR_CuPy.py:475
  * tomo_admm_dual: u  += z - x                                        methodsIR_CuPy.py:566
@@ -235,19 +253,27 @@ int tomo_roftv(int device, const float *in_dev, float *out_dev, int dx, int dy, 
 size_t tomo_pdtv_scratch_bytes(int dx, int dy, int dz, int nd, int half);
 size_t tomo_roftv_scratch_bytes(int dx, int dy, int dz, int nd);
 int tomo_release_scratch(int device);
-/* Placement of the scratch arenas (no reference counterpart: CuPy's memory pool hands out whatever block comes next).
+/* Placement of the TV scratch arenas (no reference counterpart: CuPy's memory pool hands out whatever block comes next).
  * On MI355X the speed of the plane-marching TV kernels depends on where in HBM their arrays lie (PD_TV launch at 1024^3:
- * 10.1 ms with the arena in one block, 9.1-9.3 ms in another of the same process), so an arena of
- * >= 1 GiB is chosen among up to `tries` candidate allocations held at once, each scored by a ~7 ms z-march probe; the
- * rest are freed again.  Default 6 (environment TOMO_MI355X_PLACE_TRIES), 1 = plain hipMalloc.  Candidates are only
- * taken while the device keeps 4 GiB free.
+ * 10.1 ms with the arena in one block, 9.1-9.3 ms in another of the same process; docs/kernels/placement.md).  The TV
+ * operators' own arena and the tomo_placed_scratch blocks -- nothing else: FBP spectra, Fourier and reduction scratch are
+ * plain allocations -- are therefore chosen, when they are >= 1 GiB, among up to `tries` candidate allocations held at
+ * once, each scored by a ~7 ms z-march probe; the search stops at the first candidate 8 % above an earlier one (the
+ * "fast class"), keeps the best and frees the rest.  Default 8 tries (environment TOMO_MI355X_PLACE_TRIES, at most 10),
+ * 1 = plain hipMalloc.  Bounds on what the search may hold TRANSIENTLY: the candidates together never exceed 85 % of the
+ * memory that was free when the search began, and a further candidate is only taken while the device keeps 4 GiB free;
+ * one search runs at a time per process, outside the lock that guards the other arenas.  A caller that shares the GPU
+ * with another allocator and cannot afford the transient footprint (up to tries x arena bytes) sets tries = 1.
  * tomo_placement_last reports the most recent search of this process: returns the number of candidates scored
- * (0 = none yet), *bytes the block size, *chosen the index kept, scores_GBps[i] the probe rate of candidate i. */
-/* Allocate (and place) the operators' scratch arena of this (device, stream) ahead of the first call that needs it --
+ * (0 = none yet), *bytes the block size, *chosen the index kept, scores_GBps[i] the probe rate of candidate i;
+ * tomo_placement_last_fast: 1 if the kept block cleared the 8 % rule, 0 if the tries ran out first, -1 if none ran. */
+/* Allocate (and place) the TV operators' scratch arena of this (device, stream) ahead of the first call that needs it --
  * e.g. tomo_pdtv_scratch_bytes(...) at set-up time, so that the placement search (0.1-4 s) is not part of the first
- * iteration.  Grow-only like every arena: a later call that needs more re-allocates. */
+ * iteration (RecToolsIRCuPy.FISTA / ADMM / OSEM do this before their loops).  Grow-only like every arena: a later call
+ * that needs more re-allocates. */
 int tomo_reserve_scratch(int device, size_t bytes, void *stream);
 int tomo_set_placement_tries(int tries);
+int tomo_placement_tries(void);
 /* A placed scratch block for callers that keep their own plane-marching work arrays (the z-slab drivers hold ghosted
  * copies of U, P1..3 and Input per rank; the reference's multi-GPU demo has cupy allocate them,
  * Demos/methods_IR_legacy/MultiGPU_demo.py:144-190): `bytes` of device memory owned by the library, one block per
@@ -255,6 +281,7 @@ int tomo_set_placement_tries(int tries);
  * into it die --, released by tomo_release_scratch.  Placement as above. */
 int tomo_placed_scratch(int device, int slot, size_t bytes, void *stream, void **out_dev);
 int tomo_placement_last(size_t *bytes, int *chosen, double *scores_GBps, int capacity);
+int tomo_placement_last_fast(void);
 
 /* Slab (multi-GPU) form of one PD-TV iteration on arrays that carry ghost planes:
  *   every array pointer addresses [has_lo + nz_local + has_hi][dy][dx]; the planes at either end are

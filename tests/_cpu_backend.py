@@ -51,6 +51,12 @@ class OracleTools3D:
     def sino_shape(self, os_index=None):
         return (self.nz, self.subset_size(os_index), self.nu)
 
+    def set_residual_layout(self, layout):   # the oracle keeps the planar layout
+        pass
+
+    def residual_buffer(self, os_index=None):
+        return torch.empty(self.sino_shape(os_index), dtype=torch.float32)
+
     def forward(self, vol, os_index=None, out=None):
         r = self.P.fp(np.ascontiguousarray(_np(vol)), self._sub(os_index))
         return torch.from_numpy(r) if out is None else _put(out, r)
@@ -135,6 +141,7 @@ def make_ops():
         raise AssertionError("whole-volume TV must not be called on a slab rank")
 
     m.pdtv = m.roftv = pdtv
+    m.reserve_tv_scratch = lambda *args, **kw: None   # (slab ranks never reserve whole-volume TV scratch anyway)
     return m
 
 

@@ -248,6 +248,100 @@ def test_fused_residual_and_gradient_steps(oracle, ops, g, bp_variants):
                 assert np.array_equal(host(zu_d), zn + u)
 
 
+@pytest.mark.parametrize("g", [(6, 36, 40, 22, 0.5, 3),          # nz not a multiple of 4: zero-filled tail of the last quad
+                               (37, 104, 96, 21, -0.75, 3),      # whole and ragged bricks; 37 slices = 2 bricks + 5 slices
+                               (1, 130, 130, 50, 0.0, 7),        # a single slice
+                               (16, 300, 520, 40, 3.0, 1),       # wide detector, whole-row FP form, no subsets
+                               (9, 200, 333, 512, "vec", 2)])    # dense angle set (256 x 16 FP form when forced), per-angle CoR
+@pytest.mark.parametrize("fp_variant", _v(0, 3, 2, 1))
+def test_quad_interleaved_residual_layout(oracle, ops, g, fp_variant):
+    """The private residual layout between the fused forward and back projection (TOMO_RESIDUAL_ZQUAD, round 5): what the
+    forward projector leaves is the planar residual with the four slices of a quad interleaved (zeros past nz), and the
+    three fused back-projection epilogues fed with it return bit for bit what they return for the planar layout -- which
+    test_fused_residual_and_gradient_steps pins to the oracle."""
+    P, H = make_pair(oracle, g)
+    ops.set_variant("fp", fp_variant)
+    rng = np.random.default_rng(31)
+    b = rng.random((P.nz, P.na, P.nu)).astype(np.float32)
+    wd = ops.pwls_weights(dev(b))
+    x, xo = (rng.random((P.nz, P.n, P.n)).astype(np.float32) * 0.05 for _ in range(2))
+    u = rng.standard_normal((P.nz, P.n, P.n)).astype(np.float32) * 0.01
+    linv, beta = np.float32(1 / 300.0), np.float32(0.37)
+    tau, rho, al = np.float32(0.002), np.float32(1.7), 1.6
+    for s in ([None] if P.os_number == 1 else list(range(P.os_number))):
+        idx = P.subsets[s] if s is not None else slice(None)
+        for fid in ("LS", "PWLS", "KL"):
+            assert H.residual_layout() == "planar"
+            planar = H.residual_buffer(s)
+            assert tuple(planar.shape) == H.sino_shape(s)
+            H.residual(dev(x), dev(b), wd if fid == "PWLS" else None, fid, s, planar)
+            if fid == "LS":
+                assert np.array_equal(host(planar), (P.fp(x, s) - b[:, idx]).astype(np.float32))
+            H.set_residual_layout("zquad")
+            try:
+                quad = H.residual_buffer(s)
+                nq = -(-P.nz // 4)
+                assert tuple(quad.shape) == (nq, H.subset_size(s), P.nu, 4)
+                quad.fill_(float("nan"))
+                H.residual(dev(x), dev(b), wd if fid == "PWLS" else None, fid, s, quad)
+                q = host(quad)
+                assert np.array_equal(host(H.residual_as_planar(quad, s)), host(planar)), (g, s, fid)
+                tail = q.transpose(0, 3, 1, 2).reshape(4 * nq, -1)[P.nz:]
+                assert not np.any(tail), "slices past the end of the volume must be written as zeros"
+                if fid != "LS":
+                    continue
+                for nonneg in (False, True):
+                    want, got = torch.empty_like(dev(x)), torch.empty_like(dev(x))
+                    H.set_residual_layout("planar"); H.grad_step(planar, dev(x), want, linv, nonneg, s)
+                    H.set_residual_layout("zquad"); H.grad_step(quad, dev(x), got, linv, nonneg, s)
+                    assert "quad-interleaved" in H.kernel_path("bp") or H.kernel_path("bp").startswith("direct")
+                    assert np.array_equal(host(got), host(want)), (g, s, nonneg)
+                    xt_w, xo_w, xt_g, xo_g = dev(x), dev(xo), dev(x), dev(xo)
+                    H.set_residual_layout("planar"); H.grad_step_momentum(planar, xt_w, xo_w, linv, beta, nonneg, s)
+                    H.set_residual_layout("zquad"); H.grad_step_momentum(quad, xt_g, xo_g, linv, beta, nonneg, s)
+                    assert np.array_equal(host(xt_g), host(xt_w)) and np.array_equal(host(xo_g), host(xo_w))
+                for relax_on in (False, True):
+                    z_w, zu_w, z_g, zu_g = dev(x), torch.empty_like(dev(x)), dev(x), torch.empty_like(dev(x))
+                    H.set_residual_layout("planar")
+                    H.admm_z_update(planar, z_w, dev(xo), dev(u), zu_w, tau, rho, relax_on, np.float32(1.0 - al), np.float32(al), True, s)
+                    H.set_residual_layout("zquad")
+                    H.admm_z_update(quad, z_g, dev(xo), dev(u), zu_g, tau, rho, relax_on, np.float32(1.0 - al), np.float32(al), True, s)
+                    assert np.array_equal(host(z_g), host(z_w)) and np.array_equal(host(zu_g), host(zu_w))
+                # the plain operators never follow the context's setting
+                assert np.array_equal(host(H.backward(planar, s)), P.bp(host(planar), s))
+            finally:
+                H.set_residual_layout("planar")
+
+
+def test_quad_interleaved_residual_layout_rules(oracle, ops):
+    """Who may run while the private layout is set: the ring-term residual (read by tomo_ring_gh_reduce as [detY, angles,
+    detX]) refuses, an unknown layout and a vertical CoR component are rejected, and the drivers leave the context planar."""
+    from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    from tomobar_amd.projector import HipTools3D
+    angles = np.linspace(0, np.pi, 12, endpoint=False)
+    H = HipTools3D(24, 0, 5, angles, 0.0, 24, "gpu", 0, None)
+    H.set_residual_layout("zquad")
+    vol, b = torch.zeros((5, 24, 24), device="cuda"), torch.zeros((5, 12, 24), device="cuda")
+    with pytest.raises(ValueError, match="planar"):
+        H.residual_ring(vol, b, torch.zeros((5, 24), device="cuda"), 1.0, None, H.residual_buffer(None))
+    with pytest.raises(KeyError):
+        H.set_residual_layout("columns")
+    H.set_residual_layout("planar")
+    cor = np.stack([np.zeros(12), np.full(12, 0.25)], axis=1)
+    Hv = HipTools3D(24, 0, 5, angles, cor, 24, "gpu", 0, None)
+    with pytest.raises(ValueError, match="vertical"):
+        Hv.set_residual_layout("zquad")
+    rt = RecToolsIRCuPy(24, 0, 5, 0.0, angles, 24, 0, None)
+    sino = torch.rand((5, 12, 24), device="cuda")
+    for call in (rt.FISTA, rt.ADMM):
+        call({"projection_data": sino, "data_axes_labels_order": ["detY", "angles", "detX"]}, {"iterations": 2, "lipschitz_const": 500.0})
+        assert rt.Atools.residual_layout() == "planar"
+    with pytest.raises(ValueError):   # an exception inside the loop must not leave the context in the private layout
+        rt.FISTA({"projection_data": sino, "data_axes_labels_order": ["detY", "angles", "detX"]},
+                 {"iterations": 1, "lipschitz_const": 500.0}, {"method": "no such prox", "regul_param": 1e-3, "iterations": 2})
+    assert rt.Atools.residual_layout() == "planar"
+
+
 # ------------------------------------------------------------------------------------------ TV operators
 TV_SHAPES = [(6, 9, 13), (1, 20, 17), (12, 1, 70), (10, 11, 1), (8, 8, 8), (3, 5, 131), (24, 19), (20, 70, 150)]
 # bit-identical to the oracle: 22 = shipped, opt-in (FMA-corrected roundings for float32 duals as well); dev flavour: 2 / 21 = the

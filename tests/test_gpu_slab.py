@@ -171,7 +171,8 @@ def test_placed_work_arrays_are_disjoint_views_of_one_library_block():
     from tomobar_amd.slab import SlabComm, pd_tv_slab
     dev = torch.device("cuda", 0)
     specs = [((5, 33, 70), torch.float32)] * 3 + [((5, 33, 70), torch.float16)] * 2
-    a = ops.placed_empty(specs, dev, slot=3)
+    a, lease_a = ops.placed_empty(specs, dev, slot=3)
+    assert ops.lease_is_current(lease_a)
     assert [tuple(t.shape) for t in a] == [s for s, _ in specs] and [t.dtype for t in a] == [d for _, d in specs]
     spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in a)
     for (b0, e0), (b1, e1) in zip(spans, spans[1:]):
@@ -180,8 +181,9 @@ def test_placed_work_arrays_are_disjoint_views_of_one_library_block():
         t.fill_(i + 1)
     torch.cuda.synchronize()
     assert [float(t.float().min()) for t in a] == [float(t.float().max()) for t in a] == [1.0, 2.0, 3.0, 4.0, 5.0]
-    b = ops.placed_empty(specs, dev, slot=3)
+    b, lease_b = ops.placed_empty(specs, dev, slot=3)
     assert [t.data_ptr() for t in b] == [t.data_ptr() for t in a]
+    assert ops.lease_is_current(lease_b) and not ops.lease_is_current(lease_a), "a second request supersedes the first lease"
     # the driver's result must survive the next call on the same block
     rng = np.random.default_rng(2)
     v1 = torch.from_numpy(rng.random((9, 40, 70)).astype(np.float32)).cuda()
@@ -191,3 +193,13 @@ def test_placed_work_arrays_are_disjoint_views_of_one_library_block():
     keep = r1.clone()
     r2 = pd_tv_slab(v2, comm, 0.04, 6, 0, 1, 8.0, False)
     assert torch.equal(r1, keep) and not torch.equal(r1, r2)
+    # PD_TV and ROF_TV solvers take different blocks (slots 0 / 1): running one never supersedes the other's lease ...
+    from tomobar_amd.slab import PLACED_SLOT_PD, PLACED_SLOT_ROF, PdSlab, _check_lease, _hip_alloc, rof_tv_slab
+    st = PdSlab(v1, False, False, False, None, None, alloc=_hip_alloc(PLACED_SLOT_PD))
+    rof_tv_slab(v2, comm, 0.04, 3, 0.002, False)
+    _check_lease(st)
+    assert PLACED_SLOT_PD != PLACED_SLOT_ROF
+    # ... a second PD_TV solver on the same stream does, and the first one refuses to hand out a result afterwards
+    pd_tv_slab(v2, comm, 0.04, 3, 0, 1, 8.0, False)
+    with pytest.raises(RuntimeError, match="another solver"):
+        _check_lease(st)

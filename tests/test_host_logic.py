@@ -57,20 +57,60 @@ def test_shipped_library_carries_no_ab_variants_or_probes():
 
 
 def test_placement_controls_are_host_state():
-    """Arena placement search (include/tomo_mi355x.h, tomo_set_placement_tries / tomo_placement_last): the try count is
-    validated host state, and before any arena of >= 1 GiB exists the report is empty.  (No kernel runs here.)"""
+    """Arena placement search (include/tomo_mi355x.h, tomo_set_placement_tries / tomo_placement_tries / tomo_placement_last):
+    the try count is validated host state (the test puts back what it found), and as long as no TV arena of >= 1 GiB was
+    placed in this process the report is empty.  Independent of test order: after the GPU tests a report exists and is
+    only checked for consistency.  (No kernel runs here.)"""
     import ctypes as C
-    from tomobar_amd import _lib
+    from tomobar_amd import _lib, ops
     L = _lib.lib()
-    for bad in (0, -1, 9, 100):
-        assert L.tomo_set_placement_tries(bad) == _lib.E_INVALID, bad
-        assert b"placement tries" in L.tomo_last_error()
-    for good in (1, 8, 6):
-        assert L.tomo_set_placement_tries(good) == _lib.OK
-    nbytes, chosen, scores = C.c_size_t(7), C.c_int(7), (C.c_double * 8)()
-    assert L.tomo_placement_last(C.byref(nbytes), C.byref(chosen), scores, 8) == 0
-    assert nbytes.value == 0 and chosen.value == -1
-    assert L.tomo_placement_last(None, None, None, 0) == 0
+    before = L.tomo_placement_tries()
+    assert 1 <= before <= 10
+    try:
+        for bad in (0, -1, 11, 100):
+            assert L.tomo_set_placement_tries(bad) == _lib.E_INVALID, bad
+            assert b"placement tries" in L.tomo_last_error()
+            assert L.tomo_placement_tries() == before
+        for good in (1, 10, 6):
+            assert L.tomo_set_placement_tries(good) == _lib.OK
+            assert L.tomo_placement_tries() == good == ops.placement_tries()
+    finally:
+        assert L.tomo_set_placement_tries(before) == _lib.OK
+    nbytes, chosen, scores = C.c_size_t(7), C.c_int(7), (C.c_double * 16)()
+    n = L.tomo_placement_last(C.byref(nbytes), C.byref(chosen), scores, 16)
+    if n == 0:
+        assert nbytes.value == 0 and chosen.value == -1 and L.tomo_placement_last_fast() == -1
+        assert ops.placement_last() is None
+    else:
+        assert 0 <= chosen.value < n <= 10 and nbytes.value >= 1 << 30 and L.tomo_placement_last_fast() in (0, 1)
+        assert ops.placement_last()["scores_GBps"][chosen.value] == max(ops.placement_last()["scores_GBps"])
+    assert L.tomo_placement_last(None, None, None, 0) == n
+
+
+def test_use_flavour_is_per_thread():
+    """`with use_flavour("dev")` in one thread must not redirect another thread's ops.* calls."""
+    import threading
+    from tomobar_amd import _lib
+    seen, gate, done = {}, threading.Event(), threading.Event()
+
+    def other():
+        gate.wait(10)
+        seen["flavour"], seen["lib"] = _lib.flavour(), _lib.lib().tomo_build_flavour()
+        done.set()
+
+    t = threading.Thread(target=other)
+    t.start()
+    ctx = _lib.use_flavour("dev")          # constructing the object changes nothing yet
+    assert _lib.flavour() == "shipped"
+    with ctx:
+        assert _lib.flavour() == "dev"
+        gate.set()
+        assert done.wait(10)
+    t.join()
+    assert seen == {"flavour": "shipped", "lib": b"shipped"}
+    assert _lib.flavour() == "shipped"
+    with pytest.raises(ValueError):
+        _lib.use_flavour("nightly")
 
 
 def test_no_gpu_means_loud_failure():

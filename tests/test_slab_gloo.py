@@ -290,7 +290,7 @@ def test_slab_states_take_their_arrays_from_an_allocator_hook():
         for (sh, dt), nb in zip(specs, sizes):
             out.append(block[o:o + nb].view(dt).view(tuple(sh)))
             o += nb + 64
-        return out
+        return out, None   # (arrays, lease): a private block needs no lease
 
     rng = np.random.default_rng(3)
     vol = (rng.random((9, 12, 20)) * 0.3).astype(np.float32)

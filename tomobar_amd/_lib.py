@@ -7,16 +7,19 @@ or ``make -C tomobar_amd/csrc``.
 
 from __future__ import annotations
 
+import contextvars
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtomo_mi355x.so")
 
 OK, E_INVALID, E_RUNTIME, E_NOMEM, E_NODEVICE = 0, 1, 2, 3, 4
-ABI_VERSION = 4  # TOMO_ABI_VERSION of include/tomo_mi355x.h (tests/test_host_logic.py keeps the two in step)
+ABI_VERSION = 5  # TOMO_ABI_VERSION of include/tomo_mi355x.h (tests/test_host_logic.py keeps the two in step)
 FLAG_LERP8 = 1
 FID = {"LS": 0, "PWLS": 1, "KL": 2, "RATIO": 3}
+RESIDUAL_LAYOUT = {"planar": 0, "zquad": 1}   # TOMO_RESIDUAL_* of include/tomo_mi355x.h
 
 
 class AngleRecord(C.Structure):
@@ -53,6 +56,9 @@ SIGNATURES = {
     "tomo_bp3d_fista": (_i, [_vp, _i, _vp, _vp, _vp, _f, _i, _vp]),
     "tomo_bp3d_fista_momentum": (_i, [_vp, _i, _vp, _vp, _vp, _f, _f, _i, _vp]),
     "tomo_bp3d_admm": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _f, _i, _vp]),
+    "tomo_ctx_set_residual_layout": (_i, [_vp, _i]),
+    "tomo_ctx_residual_layout": (_i, [_vp]),
+    "tomo_ctx_residual_elems": (_sz, [_vp, _i]),
     "tomo_momentum": (_i, [_vp, _vp, _vp, _f, _sz, _vp]),
     "tomo_momentum_transposed": (_i, [_vp, _vp, _vp, _vp, _f, _vp]),
     "tomo_ctx_invalidate": (_i, [_vp]),
@@ -81,6 +87,8 @@ SIGNATURES = {
     "tomo_release_scratch": (_i, [_i]),
     "tomo_reserve_scratch": (_i, [_i, _sz, _vp]),
     "tomo_set_placement_tries": (_i, [_i]),
+    "tomo_placement_tries": (_i, []),
+    "tomo_placement_last_fast": (_i, []),
     "tomo_placed_scratch": (_i, [_i, _i, _sz, _vp, C.POINTER(_vp)]),
     "tomo_placement_last": (_i, [C.POINTER(C.c_size_t), C.POINTER(_i), C.POINTER(C.c_double), _i]),
     "tomo_pdtv_iter_slab": (_i, [_i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i,
@@ -108,7 +116,10 @@ SIGNATURES = {
 
 LIB_PATHS = {"shipped": LIB_PATH, "dev": os.path.join(_HERE, "libtomo_mi355x_dev.so")}
 _handles = {}
-_flavour = "dev" if os.environ.get("TOMO_MI355X_FLAVOUR", "shipped") == "dev" else "shipped"
+_DEFAULT_FLAVOUR = "dev" if os.environ.get("TOMO_MI355X_FLAVOUR", "shipped") == "dev" else "shipped"
+# the flavour in force is per host THREAD (and per asyncio task): one thread's `with use_flavour("dev")` never redirects
+# another thread's calls to the other library and its arenas
+_flavour_var = contextvars.ContextVar("tomo_mi355x_flavour", default=_DEFAULT_FLAVOUR)
 
 
 class TomoRuntimeError(RuntimeError):
@@ -138,40 +149,52 @@ def _load(flavour: str):
     return handle
 
 
+_load_lock = threading.Lock()
+
+
 def lib():
     """The loaded shared library of the current flavour (loaded once).  Raises ImportError with build instructions if it
-    is absent.  The product always runs "shipped" (libtomo_mi355x.so); `use_flavour("dev")` -- or TOMO_MI355X_FLAVOUR=dev in
-    the environment -- points the package at libtomo_mi355x_dev.so, the build that also carries the independent kernel
-    implementations and measurement switches tests/ and tools/ compare against."""
-    h = _handles.get(_flavour)
+    is absent.  The product always runs "shipped" (libtomo_mi355x.so); `with use_flavour("dev")` -- or TOMO_MI355X_FLAVOUR=dev
+    in the environment -- points the calling thread at libtomo_mi355x_dev.so, the build that also carries the independent
+    kernel implementations and measurement switches tests/ and tools/ compare against."""
+    name = _flavour_var.get()
+    h = _handles.get(name)
     if h is None:
-        h = _handles[_flavour] = _load(_flavour)
+        with _load_lock:
+            h = _handles.get(name)
+            if h is None:
+                h = _handles[name] = _load(name)
     return h
 
 
 def flavour() -> str:
-    return _flavour
+    return _flavour_var.get()
 
 
 class use_flavour:
-    """Context manager / plain call: make `lib()` return the given flavour.  The two libraries are independent (their own
-    contexts, scratch arenas and variant switches): objects created under one flavour keep calling it (HipTools3D stores
-    its handle), so flavours can be mixed in one process as long as native handles are not passed across."""
+    """Context manager: make `lib()` return the given flavour for the calling thread inside the `with` block (the switch
+    happens in ``__enter__``, not at construction; ``enter()`` / ``exit()`` are the same for fixtures that cannot use
+    `with`).  The two libraries are independent (their own contexts, scratch arenas and variant switches): objects created
+    under one flavour keep calling it (HipTools3D stores its handle), so flavours can be mixed in one process as long as
+    native handles are not passed across."""
 
     def __init__(self, name: str):
-        global _flavour
         if name not in LIB_PATHS:
             raise ValueError(f"unknown library flavour {name!r}")
-        self.prev = _flavour
-        _flavour = name
+        self.name = name
+        self._token = None
 
     def __enter__(self):
+        self._token = _flavour_var.set(self.name)
         return lib()
 
     def __exit__(self, *exc):
-        global _flavour
-        _flavour = self.prev
+        if self._token is not None:
+            _flavour_var.reset(self._token)
+            self._token = None
         return False
+
+    enter, exit = __enter__, __exit__
 
 
 def check(rc: int, handle=None):

@@ -20,7 +20,10 @@ constexpr int BB_TX = 32, BB_TY = 16, BB_ZQ = 4, BB_AB = 8, BB_PITCH = 40;
 constexpr int BB_ITEMS = BB_AB * BB_ZQ * BB_PITCH / 256;  // 5 staging items per thread and batch
 static_assert(BB_AB * BB_ZQ * BB_PITCH == 256 * BB_ITEMS, "staging items must divide evenly");
 
-template <int EPI, bool LERP8>
+// ZQ (round 5): the sinogram is the PRIVATE residual layout [z/4][angle][u][4] that tomo_fp3d_residual leaves on a context
+// set to TOMO_RESIDUAL_ZQUAD: a staging item is ONE 16-byte load (whole 640-byte runs per angle and quad) instead of four
+// dword gathers from rows nz * na * nu floats apart; the tile in LDS, the sampling and the epilogue are unchanged.
+template <int EPI, bool LERP8, bool ZQ = false>
 __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
 {
     __shared__ float4 tile2[2][BB_AB * BB_ZQ * BB_PITCH];  // double-buffered [angle][z-quad][u], 2 x 20 KiB
@@ -67,9 +70,10 @@ __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
         it_j[m] = item % BB_PITCH;
         const int zq = (item / BB_PITCH) % BB_ZQ;
         it_aa[m] = item / (BB_PITCH * BB_ZQ);
-        it_off[m] = (unsigned)min(4 * zq, zlim) * zstride + (unsigned)it_aa[m] * (unsigned)a.nu;
+        if (ZQ) it_off[m] = (unsigned)min(zq, zlim >> 2) * zstride + (unsigned)it_aa[m] * (unsigned)a.nu;  // float4 units
+        else it_off[m] = (unsigned)min(4 * zq, zlim) * zstride + (unsigned)it_aa[m] * (unsigned)a.nu;
     }
-    const float *sino_z0 = a.sino + (size_t)z0 * zstride;
+    const float *sino_z0 = a.sino + (size_t)z0 * zstride;  // ZQ: quad z0 / 4 starts at float4 index (z0 / 4) * zstride = float z0 * zstride, too
 
     auto window = [&](int a0, int buf) {  // detector window of the brick for the 8 angles of a batch
         if (tid < BB_AB) {
@@ -90,6 +94,10 @@ __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
     auto prefetch = [&](int a0, int buf) {  // batch a0 -> registers (zero outside the detector)
         const float *base = sino_z0 + (size_t)a0 * a.nu;
         const int amax = a.na - 1 - a0;  // angle slots beyond the subset re-read the last angle (never sampled)
+        // ZQ: the quads of this z-brick from angle a0 on, as one buffer (host guarantees 4 * zstride * 16 < 2^31)
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t zq_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(reinterpret_cast<const float4 *>(sino_z0) + (size_t)a0 * a.nu), 0,
+            (int)(((unsigned)min((zlim >> 2) + 1, BB_ZQ) * zstride - (unsigned)a0 * (unsigned)a.nu) << 4), 0x00020000);
 #pragma unroll
         for (int m = 0; m < BB_ITEMS; ++m) {
             const int u = umin_s[buf][it_aa[m]] + it_j[m];
@@ -97,7 +105,15 @@ __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
             unsigned off = it_off[m] + (unsigned)min(max(u, 0), a.nu - 1);
             if (it_aa[m] > amax) off -= (unsigned)(it_aa[m] - amax) * (unsigned)a.nu;
             float4 v;
-            if (!ragged) {
+            if constexpr (ZQ) {
+                // one 16-byte buffer load; a sample outside the detector gets an out-of-range offset and reads as zero (the
+                // descriptor's range check replaces the four masks).  Slices past the end of the volume were written as
+                // zeros by the producer; quads past it re-read the last one and feed accumulators that are never stored.
+                const int boff = mk ? (int)(off << 4) : (int)0x80000000;
+                const v4f q = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(zq_rsrc, boff, 0, 0));
+                pre[m] = make_float4(q.x, q.y, q.z, q.w);
+                continue;
+            } else if (!ragged) {
                 v.x = base[off];
                 v.y = base[off + zstride];
                 v.z = base[off + 2 * zstride];

@@ -23,6 +23,7 @@ struct FpTiledArgs {
     const float *ring;       // Group-Huber offsets r_x [nz][nu] added to the residual (null: none)
     float ring_scale;        // ringGH_accelerate
     int fidelity, gathered;
+    int zquad;               // residual epilogue: out is [ceil(nz/4)][na][nu][4] (TOMO_RESIDUAL_ZQUAD, see tomo_mi355x.h)
     int wpitch;              // LDS pitch (float4 units) per staged row, <= 256 * passes <= 1024
     int nut, ngroups, nzb;   // detector tiles, angle groups, slice quads
     int bt;                  // whole-row form: detector pixels per tile = threads launched (a multiple of 64, <= 1024)
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
         if (i < ng) {
             const int k_a = ord[i];
             const tomo_angle_t t = a.tab[k_a];
+            float v4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int zz = 0; zz < 4; ++zz) {
                 const int z = z0 + zz;
@@ -254,9 +256,13 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
                             if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
                         }
                     }
-                    a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
+                    v4[zz] = val;
+                    if (!(RESID && a.zquad)) a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
                 }
             }
+            // private residual layout (TOMO_RESIDUAL_ZQUAD): the four slices of this workgroup's quad as one 16-byte word
+            if (RESID && a.zquad)
+                reinterpret_cast<float4 *>(a.out)[((size_t)zb * a.na + k_a) * a.nu + iu] = make_float4(v4[0], v4[1], v4[2], v4[3]);
         }
     }
 }
@@ -393,6 +399,7 @@ __global__ __launch_bounds__(BT) void fp_tiled_sync_kernel(FpTiledArgs a, int kc
         if (i >= ng) break;
         const int k_a = ord[i];
         const tomo_angle_t t = a.tab[k_a];
+        float v4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int zz = 0; zz < 4; ++zz) {
             const int z = z0 + zz;
@@ -412,7 +419,10 @@ __global__ __launch_bounds__(BT) void fp_tiled_sync_kernel(FpTiledArgs a, int kc
                     if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
                 }
             }
-            a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
+            v4[zz] = val;
+            if (!(RESID && a.zquad)) a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
         }
+        if (RESID && a.zquad)
+            reinterpret_cast<float4 *>(a.out)[((size_t)zb * a.na + k_a) * a.nu + iu] = make_float4(v4[0], v4[1], v4[2], v4[3]);
     }
 }

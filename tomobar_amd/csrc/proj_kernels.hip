@@ -39,7 +39,8 @@ __device__ __forceinline__ float lerp_w(float f, float fl)
 enum { EPI_PLAIN = 0, EPI_FISTA = 1, EPI_FISTA_MOM = 2, EPI_ADMM = 3 };
 
 struct BpArgs {
-    const float *sino;       // [nz][na][nu]
+    const float *sino;       // [nz][na][nu]; zquad: [ceil(nz/4)][na][nu][4] (TOMO_RESIDUAL_ZQUAD, fused epilogues only)
+    int zquad;
     const tomo_angle_t *tab; // na records
     int nz, n, nu, na;
     float *vol;              // EPI_PLAIN: output volume
@@ -156,6 +157,18 @@ __global__ __launch_bounds__(256) void bp_direct_kernel(BpArgs a)
         const float w = lerp_w<LERP8>(f, fl), omw = 1.0f - w;
         const int i0 = (int)fl;
         const bool ok0 = (i0 >= 0) && (i0 < a.nu), ok1 = (i0 + 1 >= 0) && (i0 + 1 < a.nu);
+        if (a.zquad) {  // uniform: the private residual layout, four slices per 16-byte word
+            const float4 *row4 = reinterpret_cast<const float4 *>(a.sino) + ((size_t)(z0 >> 2) * a.na + k) * a.nu;
+            const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float4 q0 = ok0 ? row4[i0] : zero4, q1 = ok1 ? row4[i0 + 1] : zero4;
+            const float t0[ZB] = {q0.x, q0.y, q0.z, q0.w}, t1[ZB] = {q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int zz = 0; zz < ZB; ++zz) {
+                acc[zz] = fmaf(omw, t0[zz], acc[zz]);
+                acc[zz] = fmaf(w, t1[zz], acc[zz]);
+            }
+            continue;
+        }
         const float *row = a.sino + ((size_t)z0 * a.na + k) * a.nu;
 #pragma unroll
         for (int zz = 0; zz < ZB; ++zz) {
@@ -289,7 +302,11 @@ int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
         a.epi_aligned = (bits & 15) == 0;
     }
     // the brick kernel addresses a 16-slice sinogram slab with 32-bit element offsets
-    const bool brick_ok = (long)a.na * a.nu < (1L << 27);
+    // (the quad layout is read through one buffer descriptor per z-brick and batch: 4 quads x 16 bytes < 2^31)
+    if (EPI == EPI_PLAIN) a.zquad = 0;  // tomo_bp3d always takes the public layout
+    const bool brick_ok = (long)a.na * a.nu < (a.zquad ? (1L << 25) : (1L << 27));
+    if (a.zquad && (((uintptr_t)a.sino) & 15) != 0)
+        return tomo_fail(TOMO_E_INVALID, "the quad-interleaved residual must be 16-byte aligned");
     if (g_variant_bp == 1 || (g_variant_bp == 0 && !brick_ok)) {
         if (g_variant_bp == 0)
             tomo_warn_once("bp_direct", "back projection: angles x detector >= 2^27 samples per slice, falling back to "
@@ -305,11 +322,21 @@ int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
         a.nzb = ceil_div(a.nz, 4 * BB_ZQ);
         const long blocks = 8L * (((long)a.nzb * a.ntx * a.nty + 7) / 8);
         if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one BP launch");
+        if constexpr (EPI != EPI_PLAIN) {
+            if (a.zquad) {
+                if (a.path) *a.path = "brick(32x16x16, quad-interleaved residual)";
+                if (lerp8) bp_brick_kernel<EPI, true, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+                else bp_brick_kernel<EPI, false, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+                TOMO_LAUNCH_CHECK();
+                return TOMO_OK;
+            }
+        }
         if (lerp8) bp_brick_kernel<EPI, true><<<(unsigned)blocks, 256, 0, st>>>(a);
         else bp_brick_kernel<EPI, false><<<(unsigned)blocks, 256, 0, st>>>(a);
     }
 #if TOMO_DEV
     else {  // variant 2 (dev flavour): the round-1 tiling with lanes along x, kept for A/B measurement
+        if (a.zquad) return tomo_fail(TOMO_E_INVALID, "bp variant 2 reads the planar residual layout only");
         if (a.path) *a.path = "tiled(64x8x16)";
         a.ntx = ceil_div(a.n, BP_TX);
         a.nty = ceil_div(a.n, BP_TY);
@@ -337,6 +364,7 @@ struct FpArgs {
     float ring_scale;
     int fidelity;
     int gathered;            // bit0: b is the gathered subset, bit1: w is
+    int zquad;               // residual epilogue: out is [ceil(nz/4)][na][nu][4] (TOMO_RESIDUAL_ZQUAD)
 };
 
 __global__ __launch_bounds__(256) void transpose_inplane_kernel(const float *__restrict__ in, float *__restrict__ out, int n)
@@ -421,6 +449,7 @@ __global__ __launch_bounds__(256) void fp_march_kernel(FpArgs a)
             acc[zz] = fmaf(w, v1, acc[zz]);
         }
     }
+    float v4[ZB] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int zz = 0; zz < ZB; ++zz) {
         if (!zok[zz]) continue;
@@ -440,8 +469,11 @@ __global__ __launch_bounds__(256) void fp_march_kernel(FpArgs a)
                 if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
             }
         }
-        a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
+        v4[zz] = val;
+        if (!(RESID && a.zquad)) a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
     }
+    if (RESID && a.zquad)
+        reinterpret_cast<float4 *>(a.out)[((size_t)(z0 >> 2) * a.na + k_a) * a.nu + iu] = make_float4(v4[0], v4[1], v4[2], v4[3]);
 }
 
 #include "fp_tiled.inl"
@@ -460,7 +492,7 @@ int fp_scratch(tomo_ctx *ctx)
 }
 
 int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const float *w, int gathered, int fidelity,
-           float *out, void *stream, const float *ring = nullptr, float ring_scale = 0.0f)
+           float *out, void *stream, const float *ring = nullptr, float ring_scale = 0.0f, int zquad = 0)
 {
     TOMO_REQUIRE(ctx != nullptr, "ctx is NULL");
     TOMO_REQUIRE(vol != nullptr && out != nullptr, "NULL data pointer");
@@ -492,6 +524,9 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
     a.nz = ctx->nz; a.n = ctx->n; a.nu = ctx->nu; a.na = s.size; a.na_full = ctx->na;
     a.out = out; a.b = b; a.w = w; a.fidelity = fidelity; a.gathered = gathered;
     a.ring = ring; a.ring_scale = ring_scale;
+    a.zquad = (b != nullptr) ? zquad : 0;
+    if (a.zquad && (((uintptr_t)out) & 15) != 0)
+        return tomo_fail(TOMO_E_INVALID, "the quad-interleaved residual must be 16-byte aligned");
     dim3 grid(ceil_div(ctx->nu, 256), s.size, ceil_div(ctx->nz, 4));
     tomo_prof_scope prof(PROF_FP, st, 1);
     ctx->last_fp_path.clear();
@@ -555,7 +590,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
             t.n_class = nc;
             t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
             t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
-            t.ring = ring; t.ring_scale = ring_scale;
+            t.ring = ring; t.ring_scale = ring_scale; t.zquad = a.zquad;
             t.wpitch = wp;
 #if TOMO_DEV
             t.probe = g_probe;
@@ -618,7 +653,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
             t.n_class = nc;
             t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
             t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
-            t.ring = ring; t.ring_scale = ring_scale;
+            t.ring = ring; t.ring_scale = ring_scale; t.zquad = a.zquad;
             t.wpitch = s.wbound16[c];
 #if TOMO_DEV
             t.probe = g_probe;
@@ -727,7 +762,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 t.n_class = nc;
                 t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
                 t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
-                t.ring = ring; t.ring_scale = ring_scale;
+                t.ring = ring; t.ring_scale = ring_scale; t.zquad = a.zquad;
                 t.wpitch = s.wbound[c];
     #if TOMO_DEV
             t.probe = g_probe;
@@ -826,7 +861,25 @@ extern "C" int tomo_fp3d_residual(tomo_ctx *ctx, int subset, const float *vol_de
                  "data_fidelity should be LS, PWLS or KL");
     TOMO_REQUIRE(fidelity != TOMO_FID_PWLS || w_full_dev != nullptr, "PWLS needs the weights");
     return fp_run(ctx, subset, vol_dev, b_full_dev, fidelity == TOMO_FID_PWLS ? w_full_dev : nullptr, gathered,
-                  fidelity, res_dev, stream);
+                  fidelity, res_dev, stream, nullptr, 0.0f, ctx ? ctx->res_layout : 0);
+}
+
+extern "C" int tomo_ctx_set_residual_layout(tomo_ctx *ctx, int layout)
+{
+    TOMO_REQUIRE(ctx != nullptr, "ctx is NULL");
+    TOMO_REQUIRE(layout == TOMO_RESIDUAL_PLANAR || layout == TOMO_RESIDUAL_ZQUAD, "unknown residual layout %d", layout);
+    ctx->res_layout = layout;
+    return TOMO_OK;
+}
+
+extern "C" int tomo_ctx_residual_layout(const tomo_ctx *ctx) { return ctx ? ctx->res_layout : -1; }
+
+extern "C" size_t tomo_ctx_residual_elems(const tomo_ctx *ctx, int subset)
+{
+    if (!ctx || subset >= ctx->os) return 0;
+    const tomo_subset &s = (subset < 0 || ctx->os == 1) ? ctx->subsets[0] : ctx->subsets[1 + subset];
+    const size_t nzr = ctx->res_layout == TOMO_RESIDUAL_ZQUAD ? (size_t)ceil_div(ctx->nz, 4) * 4 : (size_t)ctx->nz;
+    return nzr * (size_t)s.size * (size_t)ctx->nu;
 }
 
 extern "C" int tomo_momentum_transposed(tomo_ctx *ctx, const float *x_dev, const float *xold_dev, float *xt_dev, float beta,
@@ -857,6 +910,8 @@ extern "C" int tomo_fp3d_residual_ring(tomo_ctx *ctx, int subset, const float *v
                                        const float *ring_dev, float ring_scale, float *res_dev, void *stream)
 {
     TOMO_REQUIRE(b_full_dev != nullptr && ring_dev != nullptr, "projection data / ring offset pointer is NULL");
+    TOMO_REQUIRE(ctx == nullptr || ctx->res_layout == TOMO_RESIDUAL_PLANAR,
+                 "the ring-term residual is read by tomo_ring_gh_reduce in the planar layout: set TOMO_RESIDUAL_PLANAR first");
     return fp_run(ctx, subset, vol_dev, b_full_dev, nullptr, 0, TOMO_FID_LS, res_dev, stream, ring_dev, ring_scale);
 }
 
@@ -878,6 +933,7 @@ extern "C" int tomo_bp3d_fista(tomo_ctx *ctx, int subset, const float *res_dev, 
     if (rc != TOMO_OK) return rc;
     TOMO_REQUIRE(xt_dev && xout_dev, "NULL volume pointer");
     a.xt = xt_dev; a.xout = xout_dev; a.s0 = l_inv; a.nonneg = nonneg;
+    a.zquad = ctx->res_layout == TOMO_RESIDUAL_ZQUAD;
     return bp_launch<EPI_FISTA>(a, (ctx->flags & TOMO_FLAG_LERP8) != 0, as_stream(stream));
 }
 
@@ -890,6 +946,7 @@ extern "C" int tomo_bp3d_fista_momentum(tomo_ctx *ctx, int subset, const float *
     TOMO_REQUIRE(xt_dev && xold_x_dev, "NULL volume pointer");
     a.xt = xt_dev; a.xt_out = xt_dev; a.xold = xold_x_dev; a.xout = xold_x_dev;
     a.s0 = l_inv; a.s1 = beta; a.nonneg = nonneg;
+    a.zquad = ctx->res_layout == TOMO_RESIDUAL_ZQUAD;
     return bp_launch<EPI_FISTA_MOM>(a, (ctx->flags & TOMO_FLAG_LERP8) != 0, as_stream(stream));
 }
 
@@ -904,5 +961,6 @@ extern "C" int tomo_bp3d_admm(tomo_ctx *ctx, int subset, const float *res_dev, f
     a.xt = x_dev; a.xout = z_dev; a.xt_out = zu_out_dev; a.xold = u_dev;
     a.s0 = tau; a.s1 = rho; a.s2 = one_minus_alpha; a.s3 = alpha;
     a.nonneg = nonneg; a.relax_on = relax_on;
+    a.zquad = ctx->res_layout == TOMO_RESIDUAL_ZQUAD;
     return bp_launch<EPI_ADMM>(a, (ctx->flags & TOMO_FLAG_LERP8) != 0, as_stream(stream));
 }

@@ -10,6 +10,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <ctime>
 
 static thread_local char g_err[512] = "";
 
@@ -310,15 +311,22 @@ __global__ __launch_bounds__(256) void place_probe_kernel(const float *__restric
 }
 constexpr size_t PLACE_MIN_BYTES = (size_t)1 << 30;
 constexpr size_t PLACE_HEADROOM = (size_t)4 << 30;  // left free on the device while candidates are held
-constexpr int PLACE_MAX_TRIES = 8;
+constexpr double PLACE_HOLD_FRACTION = 0.85;         // ... and the candidates together never hold more than this share of
+                                                     // what was free when the search began (co-tenants keep the rest)
+constexpr int PLACE_MAX_TRIES = 10;
+constexpr int PLACE_DEFAULT_TRIES = 8;
+constexpr double PLACE_FAST_GAIN = 1.08;             // a candidate this much above an earlier one is in the fast class
 int g_place_tries = -1;
-struct place_rec { size_t bytes = 0; int tries = 0, chosen = -1; double score[PLACE_MAX_TRIES] = {0}; } g_place_last;
+struct place_rec { size_t bytes = 0; int tries = 0, chosen = -1, fast = 0; double score[PLACE_MAX_TRIES] = {0}; } g_place_last;
+// one search at a time per process (two concurrent searches would each hold their candidates), and the record above;
+// NOT the arena map's mutex: a search takes 0.1-4 s and other streams' arenas must stay reachable meanwhile
+std::mutex g_place_mu;
 
 int placement_tries()
 {
     if (g_place_tries < 0) {
         const char *e = std::getenv("TOMO_MI355X_PLACE_TRIES");
-        const int v = e ? std::atoi(e) : 6;
+        const int v = e ? std::atoi(e) : PLACE_DEFAULT_TRIES;
         g_place_tries = v < 1 ? 1 : (v > PLACE_MAX_TRIES ? PLACE_MAX_TRIES : v);
     }
     return g_place_tries;
@@ -333,29 +341,55 @@ double place_score(void *p, size_t bytes, hipStream_t st)
     const float *a = (const float *)p;
     float *b = (float *)((char *)p + (size_t)nz * ((size_t)4 << 20));
     hipEvent_t e[3];
-    for (auto &x : e) if (hipEventCreateWithFlags(&x, hipEventDefault) != hipSuccess) return 0.0;
-    place_probe_kernel<<<512 * chunks, 256, 0, st>>>(a, b, nz, zchunk);
+    int made = 0;
+    for (; made < 3; ++made)
+        if (hipEventCreateWithFlags(&e[made], hipEventDefault) != hipSuccess) break;
     double best = 0.0;
-    bool ok = true;
+    bool ok = made == 3;
+    if (ok) {
+        place_probe_kernel<<<512 * chunks, 256, 0, st>>>(a, b, nz, zchunk);
+        ok = hipGetLastError() == hipSuccess;
+    }
     for (int r = 0; r < 2 && ok; ++r) {
         ok = hipEventRecord(e[r], st) == hipSuccess;
         place_probe_kernel<<<512 * chunks, 256, 0, st>>>(a, b, nz, zchunk);
+        ok = ok && hipGetLastError() == hipSuccess;
         ok = ok && hipEventRecord(e[r + 1], st) == hipSuccess && hipEventSynchronize(e[r + 1]) == hipSuccess;
         float ms = 0.0f;
         ok = ok && hipEventElapsedTime(&ms, e[r], e[r + 1]) == hipSuccess && ms > 0.0f;
         if (ok) best = std::max(best, 2.0 * nz * (double)((size_t)4 << 20) / ms / 1e6);
     }
-    for (auto &x : e) (void)hipEventDestroy(x);
+    for (int k = 0; k < made; ++k) (void)hipEventDestroy(e[k]);
+    if (!ok) (void)hipGetLastError();
     return ok ? best : 0.0;
+}
+
+// plain allocation; a first failure is retried a few times: another process sharing the GPU may be holding placement
+// candidates for a fraction of a second (ranks that share a device in the functional multi-process tests)
+int patient_malloc(size_t bytes, void **out)
+{
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        e = hipMalloc(out, bytes);
+        if (e == hipSuccess) return TOMO_OK;
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory) break;
+        struct timespec ts = {0, 300 * 1000 * 1000};
+        nanosleep(&ts, nullptr);
+    }
+    *out = nullptr;
+    return tomo_fail(e == hipErrorOutOfMemory ? TOMO_E_NOMEM : TOMO_E_RUNTIME, "hipMalloc of %zu bytes of scratch failed: %s", bytes,
+                     hipGetErrorString(e));
 }
 
 int placed_malloc(hipStream_t st, size_t bytes, void **out)
 {
+    std::lock_guard<std::mutex> lk(g_place_mu);
     const int tries = placement_tries();
-    if (bytes < PLACE_MIN_BYTES || tries <= 1) {
-        TOMO_HIP(hipMalloc(out, bytes));
-        return TOMO_OK;
-    }
+    if (bytes < PLACE_MIN_BYTES || tries <= 1) return patient_malloc(bytes, out);
+    size_t free0 = 0, total = 0;
+    if (hipMemGetInfo(&free0, &total) != hipSuccess) { (void)hipGetLastError(); return patient_malloc(bytes, out); }
+    const size_t hold_cap = (size_t)(PLACE_HOLD_FRACTION * (double)free0);
     void *cand[PLACE_MAX_TRIES];
     place_rec rec;
     rec.bytes = bytes;
@@ -363,12 +397,15 @@ int placed_malloc(hipStream_t st, size_t bytes, void **out)
     for (int t = 0; t < tries; ++t) {
         if (t > 0) {
             size_t fr = 0, tot = 0;
-            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bytes + PLACE_HEADROOM) break;
+            if ((size_t)(t + 1) * bytes > hold_cap) break;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bytes + PLACE_HEADROOM) { (void)hipGetLastError(); break; }
         }
         void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) {
+        if (t == 0) {
+            const int rc = patient_malloc(bytes, &p);
+            if (rc != TOMO_OK) return rc;
+        } else if (hipMalloc(&p, bytes) != hipSuccess) {
             (void)hipGetLastError();
-            if (t == 0) return tomo_fail(TOMO_E_NOMEM, "hipMalloc of %zu bytes of scratch failed", bytes);
             break;
         }
         cand[t] = p;
@@ -376,7 +413,8 @@ int placed_malloc(hipStream_t st, size_t bytes, void **out)
         rec.tries = t + 1;
         if (rec.chosen < 0 || rec.score[t] > rec.score[rec.chosen]) rec.chosen = t;
         lo = (t == 0) ? rec.score[t] : std::min(lo, rec.score[t]);
-        if (t >= 1 && rec.score[rec.chosen] >= 1.08 * lo) break;  // levels 4.87 / 5.12 / 5.29 TB/s: this one is in the fast class
+        // levels 4.87 / 5.12 / 5.29 TB/s: the best is in the fast class once it beats an earlier candidate by 8 %
+        if (t >= 1 && lo > 0.0 && rec.score[rec.chosen] >= PLACE_FAST_GAIN * lo) { rec.fast = 1; break; }
     }
     for (int t = 0; t < rec.tries; ++t)
         if (t != rec.chosen) (void)hipFree(cand[t]);
@@ -389,36 +427,63 @@ int placed_malloc(hipStream_t st, size_t bytes, void **out)
 extern "C" int tomo_set_placement_tries(int tries)
 {
     TOMO_REQUIRE(tries >= 1 && tries <= PLACE_MAX_TRIES, "placement tries must be 1 .. %d", PLACE_MAX_TRIES);
-    std::lock_guard<std::mutex> lk(g_arena_mu);
+    std::lock_guard<std::mutex> lk(g_place_mu);
     g_place_tries = tries;
     return TOMO_OK;
 }
 
+extern "C" int tomo_placement_tries(void)
+{
+    std::lock_guard<std::mutex> lk(g_place_mu);
+    return placement_tries();
+}
+
 extern "C" int tomo_placement_last(size_t *bytes, int *chosen, double *scores_GBps, int capacity)
 {
-    std::lock_guard<std::mutex> lk(g_arena_mu);
+    std::lock_guard<std::mutex> lk(g_place_mu);
     if (bytes) *bytes = g_place_last.bytes;
     if (chosen) *chosen = g_place_last.chosen;
     for (int t = 0; scores_GBps && t < capacity && t < g_place_last.tries; ++t) scores_GBps[t] = g_place_last.score[t];
     return g_place_last.tries;
 }
 
-int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void **out)
+extern "C" int tomo_placement_last_fast(void)
 {
+    std::lock_guard<std::mutex> lk(g_place_mu);
+    return g_place_last.tries > 0 ? g_place_last.fast : -1;
+}
+
+// `place`: the block holds plane-marching work arrays (the TV kernels' arena, tomo_placed_scratch): choose it by the
+// placement search.  FBP spectra, Fourier and reduction scratch are plain allocations.
+int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void **out, bool place)
+{
+    void *old = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        arena_t &a = g_arenas[arena_key{device, stream, slot}];
+        if (a.bytes >= bytes) { *out = a.ptr; return TOMO_OK; }
+        old = a.ptr;
+        a.ptr = nullptr;
+        a.bytes = 0;
+    }
+    // grow outside the map's mutex: the stream's own work is the only user of this arena (two host threads driving ONE
+    // stream's scratch at once is a caller error, detected below)
+    if (old) {
+        TOMO_HIP(hipStreamSynchronize(stream));
+        TOMO_HIP(hipFree(old));
+    }
+    void *p = nullptr;
+    const int rc = place ? placed_malloc(stream, bytes, &p) : patient_malloc(bytes, &p);
+    if (rc != TOMO_OK) return rc;
     std::lock_guard<std::mutex> lk(g_arena_mu);
     arena_t &a = g_arenas[arena_key{device, stream, slot}];
-    if (a.bytes < bytes) {
-        if (a.ptr) {
-            TOMO_HIP(hipStreamSynchronize(stream));  // the only user of this arena
-            TOMO_HIP(hipFree(a.ptr));
-            a.ptr = nullptr;
-            a.bytes = 0;
-        }
-        const int rc = placed_malloc(stream, bytes, &a.ptr);
-        if (rc != TOMO_OK) { a.ptr = nullptr; return rc; }
-        a.bytes = bytes;
+    if (a.ptr != nullptr) {
+        (void)hipFree(p);
+        return tomo_fail(TOMO_E_INVALID, "two host threads grew the scratch arena of one (device, stream, slot) at the same time");
     }
-    *out = a.ptr;
+    a.ptr = p;
+    a.bytes = bytes;
+    *out = p;
     return TOMO_OK;
 }
 
@@ -427,14 +492,14 @@ extern "C" int tomo_reserve_scratch(int device, size_t bytes, void *stream)
     TOMO_REQUIRE(device >= 0 && bytes > 0, "bad scratch reservation");
     TOMO_ON_DEVICE(device);
     void *p = nullptr;
-    return tomo_arena_get(device, as_stream(stream), ARENA_MAIN, bytes, &p);
+    return tomo_arena_get(device, as_stream(stream), ARENA_TV, bytes, &p, true);
 }
 
 extern "C" int tomo_placed_scratch(int device, int slot, size_t bytes, void *stream, void **out_dev)
 {
     TOMO_REQUIRE(device >= 0 && slot >= 0 && slot < 8 && bytes > 0 && out_dev != nullptr, "bad placed-scratch request (slot 0 .. 7)");
     TOMO_ON_DEVICE(device);
-    return tomo_arena_get(device, as_stream(stream), ARENA_CALLER0 + slot, bytes, out_dev);
+    return tomo_arena_get(device, as_stream(stream), ARENA_CALLER0 + slot, bytes, out_dev, true);
 }
 
 extern "C" int tomo_release_scratch(int device)

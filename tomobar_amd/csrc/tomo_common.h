@@ -66,6 +66,7 @@ struct tomo_ctx {
     bool volT_valid = false;                  // ... valid for exactly the next forward projection of that volume
     hipStream_t volT_stream = nullptr;        // ... on the stream the copy was written on (another stream would race it)
     std::string last_fp_path, last_bp_path;   // which kernels the last FP / BP call ran (tomo_ctx_kernel_path)
+    int res_layout = 0;                       // TOMO_RESIDUAL_*: layout of the residual between tomo_fp3d_residual and tomo_bp3d_fista* / _admm
 };
 
 // one message per process and key on stderr (a slow fallback kernel was taken)
@@ -93,8 +94,8 @@ struct tomo_device_guard {
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 // grow-only scratch arena per (device, stream, slot) (tomo_release_scratch frees a device's arenas)
-enum { ARENA_MAIN = 0, ARENA_REDUCE = 1, ARENA_CALLER0 = 16 /* .. +7: tomo_placed_scratch */ };
-int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void **out);
+enum { ARENA_MAIN = 0, ARENA_REDUCE = 1, ARENA_TV = 2 /* placed: the TV operators' work arrays */, ARENA_CALLER0 = 16 /* .. +7: tomo_placed_scratch (placed) */ };
+int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void **out, bool place = false);  // place: see tomo_api.hip
 void tomo_fourier_cache_release(int device);  // cached hipFFT plans of fourier_inv.hip
 void tomo_fbp_cache_release(int device);      // cached hipFFT plans / filter tables of fbp_filter.hip
 

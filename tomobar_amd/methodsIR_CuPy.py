@@ -26,7 +26,7 @@ from numpy import float32
 
 from . import ops
 from .projector import HipTools3D, geom_size
-from .regularisersCuPy import prox_regul
+from .regularisersCuPy import prox_regul, reserve_prox_scratch
 from .supp.dicts import dicts_check
 from .supp.suppTools import _apply_horiz_detector_padding, check_kwargs, perform_recon_crop
 
@@ -134,6 +134,8 @@ class RecToolsIRCuPy:
             raise ValueError("a vertical CoR component couples the z-slabs (detector rows are resampled across slab "
                              "boundaries): reconstruct unsharded, or shard with whole-volume replicas")
         w = ops.pwls_weights(d["projection_data"], self.slab) if _data_["data_fidelity"] in ["PWLS", "SWLS"] else None
+        # the TV operators' scratch arena is allocated and placed here, at set-up, not inside the first proximal step
+        reserve_prox_scratch(self, rec_dim, r)
         return (d, a, r, x0, w, use_os)
 
     # ------------------------------------------------------------------ power method
@@ -196,39 +198,47 @@ class RecToolsIRCuPy:
         # the transposed X_t that A.momentum leaves in the projector context is a one-shot token for the NEXT residual of
         # this loop; nothing of it may survive this call (a later call's X_t can land at the same address)
         A.invalidate()
+        # on the plain LS / PWLS / KL path nobody but the back projector reads the residual: producer and consumer use the
+        # quad-interleaved layout (HipTools3D.set_residual_layout); the ring terms and the vertical CoR resampling read it
+        # as [detY, angles, detX] and keep the planar one
+        zquad = not (use_ring or use_swls) and not getattr(A, "has_vertical_shift", False)
+        A.set_residual_layout("zquad" if zquad else "planar")
         n_sub_total = a["iterations"] * self.OS_number
-        for it_no in range(a["iterations"]):
-            for sub_ind in range(self.OS_number):
-                sub = sub_ind if use_os else None
-                t_old = t
-                if sub not in res:
-                    res[sub] = torch.empty(A.sino_shape(sub), dtype=torch.float32, device=A._device)
-                if use_ring:
-                    # res = (A_s X_t - b_s) + accelerate * r_x ;  r = r_x - (1/L) sum_angles res ;  then the PWLS weights
-                    A.residual_ring(X_t, b, r_x, ring_acc, sub, res[sub])
-                    A.ring_reduce(res[sub], w if fid == "PWLS" else None, r_x, L_inv, sub, r_cur)
-                elif use_swls:
-                    A.residual(X_t, b, None, "LS", sub, res[sub])
-                    A.swls_apply(res[sub], w, float32(d["beta_SWLS"]), sub)
-                else:
-                    A.residual(X_t, b, w, fid, sub, res[sub])
-                t = float32((float32(1.0) + np.sqrt(float32(1.0) + float32(4.0) * t * t)) * float32(0.5))
-                beta = float32((t_old - float32(1.0)) / t)
-                if not has_prox:
-                    # X <- P+(X_t - grad/L) and X_t <- X + beta (X - X_old) inside the back-projection epilogue
-                    A.grad_step_momentum(res[sub], X_t, X, L_inv, beta, nonneg, sub)
-                else:
-                    A.grad_step(res[sub], X_t, X_grad, L_inv, nonneg, sub)
-                    prox_regul(self, X_grad, r, out=X_prox)
-                    if it_no * self.OS_number + sub_ind + 1 < n_sub_total:
-                        # also leaves X_t transposed for the next forward projection; after the LAST sub-iteration X_t
-                        # is never read again (the reference still computes it, methodsIR_CuPy.py:475): skipped
-                        A.momentum(X_prox, X, X_t, beta)
-                    X, X_prox = X_prox, X
-                if use_ring:
-                    # r <- soft(r, lambda) ;  r_x = r + beta (r - r_old)
-                    A.ring_update(r_cur, r_old, r_x, float32(ring_lambda), beta)
-        A.invalidate()
+        try:
+            for it_no in range(a["iterations"]):
+                for sub_ind in range(self.OS_number):
+                    sub = sub_ind if use_os else None
+                    t_old = t
+                    if sub not in res:
+                        res[sub] = A.residual_buffer(sub)
+                    if use_ring:
+                        # res = (A_s X_t - b_s) + accelerate * r_x ;  r = r_x - (1/L) sum_angles res ;  then the PWLS weights
+                        A.residual_ring(X_t, b, r_x, ring_acc, sub, res[sub])
+                        A.ring_reduce(res[sub], w if fid == "PWLS" else None, r_x, L_inv, sub, r_cur)
+                    elif use_swls:
+                        A.residual(X_t, b, None, "LS", sub, res[sub])
+                        A.swls_apply(res[sub], w, float32(d["beta_SWLS"]), sub)
+                    else:
+                        A.residual(X_t, b, w, fid, sub, res[sub])
+                    t = float32((float32(1.0) + np.sqrt(float32(1.0) + float32(4.0) * t * t)) * float32(0.5))
+                    beta = float32((t_old - float32(1.0)) / t)
+                    if not has_prox:
+                        # X <- P+(X_t - grad/L) and X_t <- X + beta (X - X_old) inside the back-projection epilogue
+                        A.grad_step_momentum(res[sub], X_t, X, L_inv, beta, nonneg, sub)
+                    else:
+                        A.grad_step(res[sub], X_t, X_grad, L_inv, nonneg, sub)
+                        prox_regul(self, X_grad, r, out=X_prox)
+                        if it_no * self.OS_number + sub_ind + 1 < n_sub_total:
+                            # also leaves X_t transposed for the next forward projection; after the LAST sub-iteration X_t
+                            # is never read again (the reference still computes it, methodsIR_CuPy.py:475): skipped
+                            A.momentum(X_prox, X, X_t, beta)
+                        X, X_prox = X_prox, X
+                    if use_ring:
+                        # r <- soft(r, lambda) ;  r_x = r + beta (r - r_old)
+                        A.ring_update(r_cur, r_old, r_x, float32(ring_lambda), beta)
+        finally:
+            A.set_residual_layout("planar")
+            A.invalidate()
         return self._finalise(X, a)
 
     # ------------------------------------------------------------------ ADMM
@@ -255,22 +265,27 @@ class RecToolsIRCuPy:
         u = self._new_vol(0.0)
         zu = self._new_vol()
         res = {}
-        for iter_no in range(a["iterations"]):
-            for sub_ind in range(self.OS_number):
-                sub = sub_ind if use_os else None
-                if sub not in res:
-                    res[sub] = torch.empty(A.sino_shape(sub), dtype=torch.float32, device=A._device)
-                A.residual(z, b, w, fid, sub, res[sub])
-                # z-update, projection, over-relaxation (from the third outer iteration on) and zu = z + u
-                A.admm_z_update(res[sub], z, x, u, zu, tau, float32(rho), iter_no > 1, float32(1.0 - alpha),
-                                float32(alpha), nonneg, sub)
-                if has_prox:
-                    prox_regul(self, zu, r_local, out=x)
-                else:
-                    x, zu = zu, x
-            ops.admm_dual(u, z, x)  # once per outer iteration (:566)
-            if a["verbose"] and np.mod(iter_no, (round)(a["iterations"] / 5) + 1) == 0:
-                print("ADMM iteration (", iter_no + 1, ") using", r["method"], "regularisation")
+        # the residual goes from the forward projector straight into the fused z-update: quad-interleaved (see FISTA)
+        A.set_residual_layout("planar" if getattr(A, "has_vertical_shift", False) else "zquad")
+        try:
+            for iter_no in range(a["iterations"]):
+                for sub_ind in range(self.OS_number):
+                    sub = sub_ind if use_os else None
+                    if sub not in res:
+                        res[sub] = A.residual_buffer(sub)
+                    A.residual(z, b, w, fid, sub, res[sub])
+                    # z-update, projection, over-relaxation (from the third outer iteration on) and zu = z + u
+                    A.admm_z_update(res[sub], z, x, u, zu, tau, float32(rho), iter_no > 1, float32(1.0 - alpha),
+                                    float32(alpha), nonneg, sub)
+                    if has_prox:
+                        prox_regul(self, zu, r_local, out=x)
+                    else:
+                        x, zu = zu, x
+                ops.admm_dual(u, z, x)  # once per outer iteration (:566)
+                if a["verbose"] and np.mod(iter_no, (round)(a["iterations"] / 5) + 1) == 0:
+                    print("ADMM iteration (", iter_no + 1, ") using", r["method"], "regularisation")
+        finally:
+            A.set_residual_layout("planar")
         return self._finalise(x, a)
 
     # ------------------------------------------------------------------ simple iterative methods

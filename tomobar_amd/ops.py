@@ -245,9 +245,11 @@ ARRAY_SKEW = 69888   # bytes between consecutive work arrays of a placed block (
 
 def placed_empty(specs, device, slot: int = 0):
     """Uninitialised work arrays inside ONE placed scratch block of the library (include/tomo_mi355x.h,
-    tomo_placed_scratch): ``specs`` is a list of (shape, dtype); returns one tensor per entry, 256-byte aligned and
-    ``ARRAY_SKEW`` apart.  The block belongs to the library (grow-only per (device, stream, slot), freed by
-    ``tomo_release_scratch``): the tensors are views for the duration of one driver call, not allocations to keep."""
+    tomo_placed_scratch): ``specs`` is a list of (shape, dtype); returns (one tensor per entry, 256-byte aligned and
+    ``ARRAY_SKEW`` apart; a lease token).  The block belongs to the library (grow-only per (device, stream, slot), freed
+    by ``tomo_release_scratch``): the tensors are views for the duration of ONE driver call, not allocations to keep, and
+    a second ``placed_empty`` on the same (device, stream, slot) supersedes them -- ``lease_is_current(token)`` tells.
+    Slots in use: 0 = PD_TV slab driver, 1 = ROF_TV slab driver (tomobar_amd/slab.py)."""
     device = torch.device(device)
     sizes, total = [], 0
     for shape, dtype in specs:
@@ -256,10 +258,28 @@ def placed_empty(specs, device, slot: int = 0):
         total += (nb + 255) // 256 * 256 + ARRAY_SKEW
     out = C.c_void_p(0)
     with torch.cuda.device(device):
-        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-        L.check(L.lib().tomo_placed_scratch(device.index or 0, int(slot), total, stream, C.byref(out)))
+        stream_id = torch.cuda.current_stream(device).cuda_stream
+        L.check(L.lib().tomo_placed_scratch(device.index or 0, int(slot), total, C.c_void_p(stream_id), C.byref(out)))
         block = torch.as_tensor(_DeviceBytes(out.value, total), device=device)
-    return [block[o:o + nb].view(dtype).view(tuple(shape)) for (o, nb), (shape, dtype) in zip(sizes, specs)]
+    key = (L.flavour(), device.index or 0, stream_id, int(slot))
+    with _lease_lock:
+        _lease_generation[key] = _lease_generation.get(key, 0) + 1
+        lease = (key, _lease_generation[key])
+    arrays = [block[o:o + nb].view(dtype).view(tuple(shape)) for (o, nb), (shape, dtype) in zip(sizes, specs)]
+    return arrays, lease
+
+
+_lease_lock = threading.Lock()
+_lease_generation = {}   # (flavour, device, stream, slot) -> how many times placed_empty handed the slot's block out
+
+
+def lease_is_current(lease) -> bool:
+    """True while nobody else has taken the same (device, stream, slot) block since ``placed_empty`` returned `lease`: the
+    arrays of an older lease may have been overwritten -- or freed, if the newer request was larger -- and must not be
+    read any more (the slab drivers check this before they copy their result out)."""
+    key, gen = lease
+    with _lease_lock:
+        return _lease_generation.get(key) == gen
 
 
 def reserve_tv_scratch(shape, device, method: str = "PD_TV", half: bool = False):
@@ -275,20 +295,26 @@ def reserve_tv_scratch(shape, device, method: str = "PD_TV", half: bool = False)
 
 
 def set_placement_tries(tries: int):
-    """Candidate allocations the library scores when it places a scratch arena of >= 1 GiB (include/tomo_mi355x.h,
-    tomo_set_placement_tries; default 6 or TOMO_MI355X_PLACE_TRIES; 1 = plain hipMalloc)."""
+    """Candidate allocations the library scores when it places a TV scratch arena of >= 1 GiB (include/tomo_mi355x.h,
+    tomo_set_placement_tries; default 8 or TOMO_MI355X_PLACE_TRIES, at most 10; 1 = plain hipMalloc)."""
     L.check(L.lib().tomo_set_placement_tries(int(tries)))
 
 
+def placement_tries() -> int:
+    return int(L.lib().tomo_placement_tries())
+
+
 def placement_last():
-    """The library's most recent arena placement search: {"bytes", "chosen", "scores_GBps"} or None if none ran yet."""
-    import ctypes as C
+    """The library's most recent arena placement search: {"bytes", "chosen", "scores_GBps", "fast"} or None if none ran
+    yet.  "fast": the kept block beat an earlier candidate by the 8 % that separates the fast class of blocks from the
+    slow one (False: the tries ran out first -- expect the TV launches 4-10 % slower)."""
     nbytes, chosen = C.c_size_t(0), C.c_int(-1)
-    scores = (C.c_double * 8)()
-    n = L.lib().tomo_placement_last(C.byref(nbytes), C.byref(chosen), scores, 8)
+    scores = (C.c_double * 16)()
+    n = L.lib().tomo_placement_last(C.byref(nbytes), C.byref(chosen), scores, 16)
     if n <= 0:
         return None
-    return {"bytes": int(nbytes.value), "chosen": int(chosen.value), "scores_GBps": [round(float(scores[i]), 1) for i in range(n)]}
+    return {"bytes": int(nbytes.value), "chosen": int(chosen.value), "scores_GBps": [round(float(scores[i]), 1) for i in range(n)],
+            "fast": bool(L.lib().tomo_placement_last_fast() == 1)}
 
 
 @contextlib.contextmanager

@@ -232,6 +232,35 @@ class HipTools3D:
             self._chk(self._lib.tomo_bp3d(self._ctx, self._sub(os_index), ops.ptr(sino), ops.ptr(out), ops.stream_ptr(sino)))
         return out
 
+    # ---- private residual layout between `residual` and `grad_step` / `grad_step_momentum` / `admm_z_update`
+    def set_residual_layout(self, layout: str):
+        """"planar" (default: the residual is the [detY, angles, detX] array every entry point documents) or "zquad": the
+        forward projector leaves the four slices of a quad interleaved, which the back projector stages with one 16-byte
+        load instead of four gathers (include/tomo_mi355x.h, TOMO_RESIDUAL_ZQUAD).  Same values, bit for bit; only the
+        fused calls above follow it, and only buffers from ``residual_buffer`` may be handed between them.  The drivers
+        switch it on around their loops and back off before they return."""
+        if layout == "zquad" and self._vshift is not None:
+            raise ValueError("the quad-interleaved residual is not available with a vertical CoR component")
+        self._chk(self._lib.tomo_ctx_set_residual_layout(self._ctx, L.RESIDUAL_LAYOUT[layout]))
+
+    def residual_layout(self) -> str:
+        code = self._lib.tomo_ctx_residual_layout(self._ctx)
+        return {v: k for k, v in L.RESIDUAL_LAYOUT.items()}[code]
+
+    def residual_buffer(self, os_index=None) -> torch.Tensor:
+        """Uninitialised buffer for the residual of a subset in the context's CURRENT residual layout."""
+        if self.residual_layout() == "planar":
+            return torch.empty(self.sino_shape(os_index), dtype=torch.float32, device=self._device)
+        n = int(self._lib.tomo_ctx_residual_elems(self._ctx, self._sub(os_index)))
+        return torch.empty((n // (4 * self.nu * self.subset_size(os_index)), self.subset_size(os_index), self.nu, 4),
+                           dtype=torch.float32, device=self._device)
+
+    def residual_as_planar(self, res, os_index=None) -> torch.Tensor:
+        """A [detY, angles, detX] copy of a residual buffer whatever layout it was written in (diagnostics / tests)."""
+        if res.dim() == 3:
+            return res
+        return res.permute(0, 3, 1, 2).reshape(-1, res.shape[1], res.shape[2])[: self.nz].contiguous()
+
     # fused forms used by the FISTA / ADMM drivers (buffers validated by the drivers)
     def residual(self, vol, b, w, fidelity: str, os_index, out, gathered: int = 0):
         """out = w_s*(A_s vol - b_s) (LS/PWLS) or 1 - b_s/max(A_s vol, 1e-8) (KL); ``gathered`` bit0/bit1: b / w is

@@ -55,6 +55,25 @@ def _prox_regul(self, X: torch.Tensor, _regularisation_: dict, out=None) -> torc
     raise ValueError(f"unknown regularisation method {method!r}: ROF_TV and PD_TV are supported")
 
 
+def reserve_prox_scratch(self, vol_shape, _regularisation_: dict) -> None:
+    """Set-up step of the iterative drivers: allocate -- and place, tomo_reserve_scratch -- the library's TV scratch arena
+    for volumes of ``vol_shape`` before the loop starts, so that the placement search (0.1-4 s, transient footprint of up
+    to `tries` x arena) is not part of the first proximal step.  No reference counterpart (CuPy's pool allocates the nine
+    arrays inside every call, regularisersCuPy.py:220-232).  Nothing to do without a TV method, and in z-slab mode the
+    slab drivers take their own placed block (slab.py)."""
+    method = _regularisation_.get("method")
+    if method is None or getattr(self, "slab", None) is not None:
+        return
+    shape = tuple(int(v) for v in vol_shape)
+    if len(shape) == 3 and 1 in shape:       # a singleton axis runs the 2D kernels (_check_if_input_2d_or_3d)
+        i = shape.index(1)
+        shape = shape[:i] + shape[i + 1:]
+    kind = "ROF_TV" if "ROF_TV" in method else ("PD_TV" if "PD_TV" in method else None)
+    if kind is None:
+        return
+    ops.reserve_tv_scratch(shape, f"cuda:{self.Atools.device_index}", kind, bool(_regularisation_.get("half_precision", False)))
+
+
 def _prepare(data, gpu_id: int):
     if gpu_id < 0:
         raise ValueError("The gpu_device must be a positive integer or zero")

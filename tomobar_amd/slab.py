@@ -335,10 +335,14 @@ class PdSlab:
         # only the initial duals need zeros; every other plane that influences an output is copied, received or
         # overwritten before it is read (the outermost Input ghost only feeds warm-up values that are discarded)
         # `alloc(specs, device)` (the HIP drivers pass ops.placed_empty): the nine work arrays as views of one block the
-        # library places in HBM ("placement"); default: nine allocations of the caller's allocator
+        # library places in HBM (docs/kernels/placement.md); default: nine allocations of the caller's allocator
         shape = (planes, dy, dx)
         specs = [(shape, torch.float32)] * 3 + [(shape, pd)] * 6
-        arrs = alloc(specs, dev) if alloc is not None else [torch.empty(sh, dtype=dt, device=dev) for sh, dt in specs]
+        self.lease = None
+        if alloc is not None:
+            arrs, self.lease = alloc(specs, dev)
+        else:
+            arrs = [torch.empty(sh, dtype=dt, device=dev) for sh, dt in specs]
         self.placed = alloc is not None   # the arrays belong to the library's block: results leave it as copies
         self.inp = arrs[0]
         self.inp[self.lo:self.lo + nzl] = data
@@ -444,9 +448,25 @@ class PdSlab:
         return [self.inp[h:h + GHOST]] if self.has_hi else []
 
 
-def _hip_alloc(specs, device):
-    from . import ops
-    return ops.placed_empty(specs, device, slot=0)
+PLACED_SLOT_PD, PLACED_SLOT_ROF = 0, 1   # one placed block per operator: a PD_TV and a ROF_TV solver on one stream never alias
+
+
+def _hip_alloc(slot):
+    def alloc(specs, device):
+        from . import ops
+        return ops.placed_empty(specs, device, slot=slot)
+    return alloc
+
+
+def _check_lease(st):
+    """The work arrays are views of a library-owned block (ops.placed_empty): refuse to read a result out of a block that
+    another solver on the same (device, stream, slot) has taken since -- e.g. two slab solvers interleaved on one stream."""
+    if getattr(st, "lease", None) is not None:
+        from . import ops
+        if not ops.lease_is_current(st.lease):
+            raise RuntimeError("the placed scratch block of this slab solver was handed to another solver on the same "
+                               "(device, stream) before its result was read: run slab solvers one after the other per "
+                               "stream, or on separate streams")
 
 
 def _ptr3(ts):
@@ -486,7 +506,7 @@ def pd_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, m
     lt = np.float32(tau / regularisation_parameter)
     comm.validate_slabs(data.shape[0], GHOST)
     st = PdSlab(data, comm.has_lo, comm.has_hi, half_precision, pair_fn or _hip_pd_pair, step_fn or _hip_pd_step,
-                alloc=_hip_alloc if (pair_fn is None and step_fn is None and data.is_cuda) else None)
+                alloc=_hip_alloc(PLACED_SLOT_PD) if (pair_fn is None and step_fn is None and data.is_cuda) else None)
     comm.exchange(st.initial_send_down(), st.initial_recv_down(), st.initial_send_up(), st.initial_recv_up())
     edge_ranges, interior = st.boundary_ranges()
     # Overlap: the planes the neighbours wait for are computed first (two thin launches), their exchange runs on RCCL's
@@ -511,6 +531,7 @@ def pd_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, m
         if more:
             b = st.cur
             comm.exchange(st.send_down(b), st.recv_down(b), st.send_up(b), st.recv_up(b))
+    _check_lease(st)
     res = st.result()  # a view of the last output buffer (the buffer lives as long as the view)
     if iterations == 0:
         res = data
@@ -535,7 +556,11 @@ class RofSlab:
         dev = data.device
         self.half = bool(half)
         specs = [((planes, dy, dx), torch.float32)] * 3
-        arrs = alloc(specs, dev) if alloc is not None else [torch.empty(sh, dtype=dt, device=dev) for sh, dt in specs]
+        self.lease = None
+        if alloc is not None:
+            arrs, self.lease = alloc(specs, dev)
+        else:
+            arrs = [torch.empty(sh, dtype=dt, device=dev) for sh, dt in specs]
         self.inp = arrs[0]
         self.inp[self.lo:self.lo + nzl] = data
         self.U = arrs[1:3]
@@ -588,7 +613,7 @@ def rof_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, 
                 half_precision=False, step_fn: Optional[Callable] = None, out=None, overlap: bool = True):
     comm.validate_slabs(data.shape[0])
     st = RofSlab(data, comm.has_lo, comm.has_hi, half_precision, step_fn or _hip_rof_step,
-                 alloc=_hip_alloc if (step_fn is None and data.is_cuda) else None)
+                 alloc=_hip_alloc(PLACED_SLOT_ROF) if (step_fn is None and data.is_cuda) else None)
     lam, tau = np.float32(regularisation_parameter), np.float32(time_marching_parameter)
     comm.exchange(st.send_down(0), st.recv_down(0), st.send_up(0), st.recv_up(0))
     edge_ranges, interior = st.boundary_ranges()
@@ -606,6 +631,7 @@ def rof_tv_slab(data: torch.Tensor, comm, regularisation_parameter, iterations, 
         st.step(it, lam, tau)
         if more:
             comm.exchange(st.send_down(b), st.recv_down(b), st.send_up(b), st.recv_up(b))
+    _check_lease(st)
     res = st.local(st.U[iterations & 1])
     if out is not None:
         out.copy_(res)

@@ -16,11 +16,30 @@ xo = torch.rand_like(xt)
 zu = torch.empty_like(xt)
 u = torch.rand_like(xt)
 out = torch.empty_like(xt)
+H.set_residual_layout("zquad")
+resq = H.residual_buffer(None)
+resq.copy_(torch.rand_like(resq))
+H.set_residual_layout("planar")
+
+
+def quad(fn):
+    def run():
+        H.set_residual_layout("zquad")
+        try:
+            fn()
+        finally:
+            H.set_residual_layout("planar")
+    return run
+
+
 cases = {
     "plain": lambda: H.backward(res, None, out=out),
     "fista": lambda: H.grad_step(res, xt, out, 1e-4, True, None),
+    "fista (quad residual)": quad(lambda: H.grad_step(resq, xt, out, 1e-4, True, None)),
     "fista+momentum": lambda: H.grad_step_momentum(res, xt, xo, 1e-4, 0.5, True, None),
+    "fista+mom. (quad)": quad(lambda: H.grad_step_momentum(resq, xt, xo, 1e-4, 0.5, True, None)),
     "admm": lambda: H.admm_z_update(res, xo, xt, u, zu, 1e-4, 1.0, True, 0.2, 0.8, True, None),
+    "admm (quad residual)": quad(lambda: H.admm_z_update(resq, xo, xt, u, zu, 1e-4, 1.0, True, 0.2, 0.8, True, None)),
 }
 ts = {k: [] for k in cases}
 for rnd in range(5):
@@ -32,4 +51,4 @@ for rnd in range(5):
         e0.record(); fn(); fn(); e1.record(); torch.cuda.synchronize()
         ts[k].append(e0.elapsed_time(e1) / 2)
 for k, v in ts.items():
-    print(f"BP {k:15s}: median {statistics.median(v):7.3f} min {min(v):7.3f} ms", flush=True)
+    print(f"BP {k:22s}: median {statistics.median(v):7.3f} min {min(v):7.3f} ms", flush=True)

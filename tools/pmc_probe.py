@@ -1,5 +1,5 @@
 """Small fixed workloads for rocprofv3 --pmc passes (one kernel class per invocation, few launches).
-usage: python tools/pmc_probe.py <what> [N] [NZ] [NA]   what in {pdtv0,pdtv1,pdtv0h,roftv,bp0,bp1,fp,momentum,fourier}"""
+usage: python tools/pmc_probe.py <what> [N] [NZ] [NA]   what in {pdtv0,pdtv1,pdtv0h,roftv,bp0,bp1,bpq,fp,fpq,momentum,fourier}"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -46,7 +46,14 @@ elif what == "momentum":
 else:
     H = HipTools3D(N, 0, NZ, np.linspace(0, np.pi, NA, endpoint=False), 0.0, N, "gpu", 0, None)
     sino = torch.rand((NZ, NA, N), device="cuda")
-    if what.startswith("bp"):
+    if what in ("bpq", "fpq"):   # the fused pair as the FISTA loop runs it: residual in the quad-interleaved layout (round 5)
+        H.set_residual_layout("zquad")
+        res = H.residual_buffer(None)
+        for _ in range(2 if what == "fpq" else 1):
+            H.residual(vol, sino, None, "LS", None, res)
+        for _ in range(3 if what == "bpq" else 0):
+            H.grad_step(res, vol, out, 1e-4, True, None)
+    elif what.startswith("bp"):
         ops.set_variant("bp", int(what[2]))
         for _ in range(3):
             H.backward(sino, None, out=out)

@@ -2,7 +2,8 @@
 usage: python tools/update_pmc_traffic.py <pdtv-dir> <others-dir> <profile-name>
   <pdtv-dir>   gpurun_out/pmc_<tag> holding pdtv0_g0 (FETCH_SIZE) / pdtv0_g1 (WRITE_SIZE) of a 9-iteration prox
                (first + middle + last launch), and the same for pdtv0h (binary16 duals)
-  <others-dir> the same for roftv, bp0, fp
+  <others-dir> the same for roftv, bpq, fpq (the fused pair as the FISTA loop runs it: residual epilogue of the forward
+               projector, gradient-step epilogue of the back projector, residual handed over quad-interleaved)
 FETCH_SIZE is doubled (MI355X_MICROARCH.md: 128-B requests are counted as 64 B); values are KiB."""
 import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -46,8 +47,10 @@ out["pdtv_half"] = {
     "sources_sha16": bench.source_hash("pdtv"), "profile": profile}
 for name, what, keys, wl in (
         ("roftv", "roftv", ["rof_"], "1024^3, 1 iteration/launch (rof_zmarch, shipped build: FMA-corrected reference roundings); later launches"),
-        ("bp", "bp0", ["bp_brick"], "1024^3, 75 angles (one subset), bp_brick_kernel"),
-        ("fp", "fp", ["fp_tiled", "transpose"], "1024^3, 75 angles (one subset): 2 launches of fp_tiled_kernel<...,1024> + the in-plane transpose")):
+        ("bp", "bpq", ["bp_brick"], "1024^3, 75 angles (one subset), bp_brick_kernel with the FISTA gradient-step epilogue, "
+                                    "quad-interleaved residual (what bench.py times)"),
+        ("fp", "fpq", ["fp_tiled", "transpose"], "1024^3, 75 angles (one subset): 2 launches of fp_tiled_kernel<...,1024> with the "
+                                                 "residual epilogue (quad-interleaved output) + the in-plane transpose")):
     fs = ws = 0.0
     for k in keys:
         fv, wv = vals(ot_dir, what, 0, k), vals(ot_dir, what, 1, k)
