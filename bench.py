@@ -277,7 +277,7 @@ def live_traffic(dom, args, n, nz, sub):
     """HBM traffic per launch of the dominant kernel, measured NOW on this box: two separate `rocprofv3 --pmc` passes
     (FETCH_SIZE, then WRITE_SIZE; kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over
     tools/pmc_probe.py, which launches that kernel on the bench's own shape in a child process.  FETCH_SIZE is doubled (the
-    guide's gfx950 correction: 128-B requests are tallied as 64 B; calibrated on a dword stream in profiles/r1_pdtv_pmc.txt),
+    guide's gfx950 correction: 128-B requests are tallied as 64 B; calibrated on a dword stream in profiles/archive/r1_pdtv_pmc.txt),
     values are KiB.  Returns (bytes per launch, description) or (None, reason)."""
     import csv
     import glob

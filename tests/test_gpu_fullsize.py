@@ -293,7 +293,7 @@ def test_config4_geometry_fista_ring_end_to_end_against_oracle(oracle, pd_arith)
     """BASELINE configs[4]'s loop on its own geometry (2560-wide detector, 1800 angles in 12 subsets, FISTA-OS + PD_TV +
     Group-Huber ring term) on a 2-slice volume, one outer iteration: the 3-pass whole-row forward projector with the
     ring-offset residual epilogue, the offsets' reduction / shrinkage, brick back projector, PD_TV -- bit for bit
-    against the oracle's run of the same loop (the ring term itself is formula-level)."""
+    against the oracle's run of the same loop (the ring term itself is formula-level, DESIGN.md section 2 "Oracle")."""
     from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
     n, nz, na, os_n = 2560, 2, 1800, 12
     angles = np.linspace(0, np.pi, na, endpoint=False)

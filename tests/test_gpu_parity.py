@@ -607,7 +607,7 @@ def test_tv_large_odd_shapes(oracle, ops, seed, pd_variants):
 
 def test_scratch_arena_placement_search(oracle, ops):
     """The library picks its large scratch arenas among several candidate allocations scored by a z-march probe (on MI355X
-    the same PD_TV launch runs 10 % faster or slower depending on where its arena lies).  The search
+    the same PD_TV launch runs 10 % faster or slower depending on where its arena lies, docs/kernels/placement.md).  The search
     must be invisible in the results: same bits with it on (3 candidates) and off, and the report must describe it."""
     from tomobar_amd import _lib
     from tomobar_amd.regularisersCuPy import PD_TV_cupy

@@ -123,7 +123,7 @@ def test_shipped_roftv_on_noise_against_both_reference_builds(oracle):
     2.5e-5 .. 4.5e-5 there.  The shipped build now reproduces the roundings of the contracted reference build exactly:
     bit-identical to libref_tv_fma.so's output (float32 D fields) on every one of these inputs, hence exactly as far
     from the uncontracted build as the reference itself is.  The table is written to gpurun_out/ (committed under
-    profiles/r3_rof_noise_reference_spread.txt)."""
+    profiles/archive/r3_rof_noise_reference_spread.txt)."""
     from tomobar_amd import ops
     from tomobar_amd.regularisersCuPy import ROF_TV_cupy
     Loff, Lfma = load("libref_tv.so"), load("libref_tv_fma.so")

@@ -4,7 +4,7 @@
 // apart) x 16 slices = 32 accumulators.  For every batch of 8 angles the part of the sinogram the brick can touch
 // (<= 31|cos| + 15|sin| + 2 < 38 detector samples per angle and slice) is staged in LDS as float4 over z, then every
 // tap is one ds_read_b128 serving 4 slices.  What the PMC counters said about the first tiled kernel (64 x 8 brick,
-// lanes along x; profiles/r1_bp_fp_pmc.txt) and what this kernel does about it:
+// lanes along x; profiles/archive/r1_bp_fp_pmc.txt) and what this kernel does about it:
 //   * half of its VALU instructions were staging (div/mod item decoding, 64-bit addresses, four guarded loads per
 //     item): here an item's LDS slot and global offset are loop invariants, loads are unconditional on clamped
 //     addresses (slices >= nz are fed by a valid slice and never stored), 5 items per thread instead of 9;

@@ -38,7 +38,7 @@ struct FpTiledArgs {
 // whole detector row of a 1024-wide problem, so every volume row is staged once per angle group instead of once per
 // (angle group, detector tile) with overlapping windows -- the 12-strided angles of an ordered subset spread a 256-pixel
 // tile's window to ~480 columns, i.e. 4 x 480 instead of 1030 per row; measured L2->fabric traffic 55 GB per call with
-// 256-pixel tiles (profiles/r1_bp_fp_pmc.txt) because the 12-20 workgroups sharing a slice quad drift apart.
+// 256-pixel tiles (profiles/archive/r1_bp_fp_pmc.txt) because the 12-20 workgroups sharing a slice quad drift apart.
 // PASSES = ceil(wpitch / BT) column passes per staged row; KC = M / PASSES rows per chunk (compile-time so that the
 // staging index arithmetic is free of integer divisions).
 // M = float4 staging items per thread and chunk (register prefetch depth).  DB: double-buffered tile, one barrier per

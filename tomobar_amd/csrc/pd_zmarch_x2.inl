@@ -2,7 +2,7 @@
 // tv_kernels.hip (uses PdArgs, DualIO, pd_dual, pd_primal).
 //
 // One iteration moves 36 B/voxel (read Input, U, P1..3; write U, P1..3) and is bound by the number of 128-B / 64-B
-// fabric requests (profiles/r1_pdtv_pmc.txt).  Here stage A (iteration n -> n+1) runs one plane ahead of stage B
+// fabric requests (profiles/archive/r1_pdtv_pmc.txt).  Here stage A (iteration n -> n+1) runs one plane ahead of stage B
 // (n+1 -> n+2) inside the same z-march, so U^{n+1} and P^{n+1} never leave the register file:
 //
 //   step t:  stage A on plane t    : loads U^n(t+1), P^n(t), Input(t);   P^{n+1}(t), U^{n+1}(t)      (registers only)

@@ -2,7 +2,7 @@
 // K stages.  Included inside the anonymous namespace of tv_kernels.hip (uses PdArgs, DualIO, pd_dual_t, pd_primal_t).
 //
 // One iteration moves 36 B/voxel and the two-iteration kernel is HBM-bound once the IEEE divide / sqrt are relaxed
-// (profiles/r2_b_pdtv_tile_vs_x2_pmc.txt), so the only lever left is bytes per iteration.  Stage s (iteration n+s ->
+// (profiles/archive/r2_b_pdtv_tile_vs_x2_pmc.txt), so the only lever left is bytes per iteration.  Stage s (iteration n+s ->
 // n+s+1) works on plane t-s at step t of the z-march; what it needs from stage s-1 (U^{n+s} of planes t-s-1, t-s, t-s+1
 // and P^{n+s} of plane t-s) is still in registers, so HBM sees one read of Input, U, P1..3 and one write of U, P1..3 per
 // K iterations.  The price is the halo every wave re-computes: stage s evaluates its duals on rows -(K-s) .. RY+(K-s)-2

@@ -281,7 +281,7 @@ static std::map<arena_key, arena_t> g_arenas;
 
 // ---- placement of large scratch blocks (round 4).  On MI355X the speed of a plane-marching kernel depends on WHERE in HBM
 // its arrays were allocated: the same PD_TV launch on the same volume takes 10.1 ms with its scratch arena in one block of
-// device memory and 9.1-9.3 ms in another (same process, same kernel, profiles/r4z_pd_arena_placement.txt); a flat copy does
+// device memory and 9.1-9.3 ms in another (same process, same kernel, profiles/archive/r4z_pd_arena_placement.txt); a flat copy does
 // not see the difference (6.1-6.3 TB/s everywhere), a z-march over one array of 4 MB planes does (4.9 vs 5.3 TB/s per 8.6 GB
 // chunk, two levels, roughly a quarter of the device in the slow one and a different quarter in every process).  So a block
 // of >= 1 GiB is chosen among up to `tries` candidate allocations held at the same time: each is scored with a z-march

@@ -280,7 +280,7 @@ __device__ __forceinline__ float mk_sqrt(float x)
     return fmaf(fmaf(-q, q, x), h, q);
 }
 // 1.0f / q correctly rounded: v_rcp_f32 (1 ulp) + ONE Newton step.  On gfx950 that equals the IEEE quotient for every one of
-// the 1 677 721 601 floats in [2^-100, 2^100] (tools/probes/recip_allones_probe.hip, profiles/r4d_recip_allones_probe.txt;
+// the 1 677 721 601 floats in [2^-100, 2^100] (tools/probes/recip_allones_probe.hip, profiles/archive/r4d_recip_allones_probe.txt;
 // round 3 used two steps).  The textbook counter-example q = 0x1.fffffep+k -- where a v_rcp that returned the 1-ulp-low
 // 2^-(k+1) would leave the Newton update on an exact tie -- does not occur: this hardware's v_rcp_f32 returns RN(1/q)
 // there in every binade.
@@ -435,7 +435,7 @@ __device__ __forceinline__ void pd_primal_block(float (&out)[NB], const float (&
 //   variant 22 (shipped, opt-in): the reference's roundings through FMA correction steps (FAST = 2) for float32 duals as
 //              well, same tilings: bit-identical to the oracle.  Round 4, same-box pairs, 30-iteration prox at 1024^3: 10.5-10.7 ms
 //              per three-iteration launch against 9.2 (one box, +16 %; 0.636 vs 0.717 outer iterations/s on the bench,
-//              profiles/r4d_bench_exact_vs_relaxed.txt) or 10.05 (another box, +4.6 %; 0.645 vs 0.668) relaxed -- the ~390
+//              profiles/archive/r4d_bench_exact_vs_relaxed.txt) or 10.05 (another box, +4.6 %; 0.645 vs 0.668) relaxed -- the ~390
 //              extra VALU instructions per plane of the correction chains (two quarter-rate transcendentals and 13
 //              dependent FMAs per dual row) on a kernel that is bound by instruction issue.  That is why it is not the default.
 //   dev flavour: 3 = relaxed arithmetic for both dual types; 2 = the compiler's IEEE sqrt / divide sequences, two iterations
@@ -474,7 +474,7 @@ int pd_xk3_launch(const PdArgs &a, int variant, hipStream_t st)
     // argument (0 or -inf; "u < -inf" is never true, so the iterate passes through exactly as the code without the test
     // would leave it).  The separate no-clip instantiation of the isotropic kernel allocated 256 registers with 154 spilled
     // and ran 15 % slower than the one with the test (11.9 vs 10.4 ms per launch), and with the threshold in a scalar register
-    // the compiler's schedule of the clipping kernel itself is 2.8 % faster (profiles/r4y_pd_instantiations.txt).  The exact
+    // the compiler's schedule of the clipping kernel itself is 2.8 % faster (profiles/archive/r4y_pd_instantiations.txt).  The exact
     // builds keep their two instantiations: there the no-clip one is the faster by 3 %.
     PdArgs b = a;
     b.nn_thr = NN ? 0.0f : -__builtin_inff();
@@ -544,7 +544,7 @@ int pd_launch(const PdArgs &a0, int variant, hipStream_t st)
     PdArgs a = a0;
     const int nout = a.out_end - a.out_begin;
     if (nout <= 0 || a.dx <= 0 || a.dy <= 0) return TOMO_OK;
-    // measured on MI355X, 1024^3 f32 duals (profiles/r1_pdtv_pmc.txt): 4x2 waves x 8 rows, lockstep = 8.6 ms;
+    // measured on MI355X, 1024^3 f32 duals (profiles/archive/r1_pdtv_pmc.txt, docs/measurement_log.md): 4x2 waves x 8 rows, lockstep = 8.6 ms;
     // 4x4 waves x 4 rows = 9.2 ms; 4x1 x 8 rows = 8.7 ms; unsynchronised waves (1x4, 4 rows) = 12.3-14 ms.
     // The arithmetic of an iteration never depends on how a run is cut into launches (slabs cut it differently): the
     // single-iteration kernel follows the variant's arithmetic like the fused ones.
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256) void rof_pervoxel_kernel(RofArgs a)
 // dev flavour: 2 = the same roundings through the compiler's IEEE sqrt / divide expansions (independent check, 4.4 ms);
 //              3 = relaxed arithmetic (float32 sum + v_rsq_f32, 2.85 ms) -- measurement only: the D normalisation has a gain
 //              of ~1e4 on noise-dominated data, where one-ulp differences grow to 2.5e-5 .. 4.5e-5 after 60 iterations
-//              (profiles/r3_rof_variants.txt), beyond the 1e-5 parity bar;  4 = refined v_rsq / v_rcp (no better than 3);
+//              (profiles/archive/r3_rof_variants.txt), beyond the 1e-5 parity bar;  4 = refined v_rsq / v_rcp (no better than 3);
 //              1 = per-voxel kernel (independent implementation)
 template <int ND, bool HALF>
 int rof_zmarch_dispatch(const RofArgs &a, int variant, hipStream_t st)

@@ -1,5 +1,5 @@
 // NOT part of the build.  Round-2 experiment (PD_TV workgroup tile with LDS row halos), measured slower than the per-wave-halo
-// kernels in every shape (profiles/r2_b_pdtv_tile_vs_x2_pmc.txt).  To rebuild it: include this file in
+// kernels in every shape (docs/kernels/pd_tv.md, profiles/archive/r2_b_pdtv_tile_vs_x2_pmc.txt).  To rebuild it: include this file in
 // tv_kernels.hip after pd_zmarch2.inl and dispatch pd_tile_launch<T, NN, AN, FAST, 4, 1, 8> from pd_multi_launch.
 // PD_TV, TWO Chambolle-Pock iterations per pass through HBM, workgroup TILE with the row halos shared through LDS
 // (3D only; default).  Included inside the anonymous namespace of tv_kernels.hip (uses PdArgs, DualIO, pd_dual, pd_primal).
@@ -8,7 +8,7 @@
 // intermediate U / P never leave the chip), but the row halos are no longer RE-COMPUTED by every wave.  In the x2 kernel
 // a wave produced RY = 4 output rows from 8 loaded rows of U, 7 of P1..3, 6 of Input and evaluated 7 + 5 dual rows:
 // 35 row loads and 12 dual evaluations per 8 output-row-iterations; counters: 1.4-1.5x the compulsory read traffic
-// (profiles/r1_pdtv_pmc.txt).  Here a workgroup is a stack of WY waves that owns a tile of WY*RY consecutive rows; a wave
+// (profiles/archive/r1_pdtv_pmc.txt).  Here a workgroup is a stack of WY waves that owns a tile of WY*RY consecutive rows; a wave
 // loads and updates ONLY its own RY rows and hands the one row its neighbour needs (U^n, U^{n+1}: first and last row;
 // P2^{n+1}, P2^{n+2}: last row) through LDS.  Only the tile as a whole carries a two-row halo top and bottom:
 //     rows computed per output row  (WY*RY) / (WY*RY - 4) = 32/28 = 1.14   (x2 kernel: 1.75 loads, 1.5 duals)

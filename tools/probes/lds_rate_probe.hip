@@ -14,7 +14,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // MODE 0: reads only; 1: + 2 v_pk_fma_f32 per read, consuming the PREVIOUS batch (so no wait inside a batch);
 // MODE 2: + 2 v_pk_fma_f32 + 2 plain VALU (v_fmac_f32) per read = the back projector's real ratio, 4.1 VALU per LDS
-//         instruction (SQ_INSTS_VALU 2.90e9 / SQ_INSTS_LDS 7.03e8, profiles/r4b_fp_lane_permutation_ab.txt)
+//         instruction (SQ_INSTS_VALU 2.90e9 / SQ_INSTS_LDS 7.03e8, profiles/archive/r4b_fp_lane_permutation_ab.txt)
 // STRIDE16: lane stride in 16-B slots x 100 (100 = unit stride, 141 = FP's worst case)
 #define USE(r) acc0 = __builtin_elementwise_fma(w, v2f{r.x, r.y}, acc0); acc1 = __builtin_elementwise_fma(w, v2f{r.z, r.w}, acc1);
 #define USE2(r) acc2 = __builtin_elementwise_fma(w, v2f{r.x, r.y}, acc2); acc3 = __builtin_elementwise_fma(w, v2f{r.z, r.w}, acc3);
