@@ -16,18 +16,50 @@
 // Accumulation order (angles ascending, tap 0 then tap 1, fmaf) is that of the oracle: results are bit-identical.
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int BB_TX = 32, BB_TY = 16, BB_ZQ = 4, BB_AB = 8, BB_PITCH = 40;
-constexpr int BB_ITEMS = BB_AB * BB_ZQ * BB_PITCH / 256;  // 5 staging items per thread and batch
-static_assert(BB_AB * BB_ZQ * BB_PITCH == 256 * BB_ITEMS, "staging items must divide evenly");
+constexpr int BB_TX = 32, BB_TY = 16, BB_ZQ = 4, BB_AB = 8;
+// columns per (angle, z-quad) row of the tile.  A brick sees at most 31|cos| + 15|sin| <= 34.5 detector pixels plus the
+// second tap and the floor: 37 columns.  Planar staging: 40 (5 items per thread exactly).  Quad-interleaved staging (LDS-DMA,
+// no register budget to respect): 39, so that two tile buffers + the window table stay within 160 KiB / 4 = 40 960 B and
+// FOUR workgroups share a CU (the last of its 5 item rounds is 224 of 256 threads).
+template <bool ZQ> constexpr int bb_pitch = ZQ ? 39 : 40;
+template <bool ZQ> constexpr int bb_nitems = BB_AB * BB_ZQ * bb_pitch<ZQ>;
+template <bool ZQ> constexpr int bb_items = (bb_nitems<ZQ> + 255) / 256;  // staging items per thread and batch (5)
+static_assert(bb_nitems<false> == 256 * bb_items<false>, "planar staging items must divide evenly");
+typedef __attribute__((address_space(3))) void *bb_lds_ptr;
+// One LDS-DMA: 16 bytes per lane from buffer `rs` at byte offset `voff` (out of range -> zeros) to LDS byte address
+// `lds_addr` + 16 * lane (`lds_addr` wave-uniform).  Issued through inline assembly on purpose: hipcc tracks an LDS-DMA issued
+// by the builtin as a pending LDS WRITE and, unless it can prove the addresses apart (it cannot: the tile buffers alternate
+// and the window slots rotate by run-time indices), waits vmcnt(0) before the next ds_read -- i.e. it drained the staging of
+// batch b+1 before the first sample of batch b (seen in the ISA).  The kernel orders the hand-over itself: s_waitcnt vmcnt(0)
+// + the batch barrier before a tile is sampled.  Loads return in order, so the compiler's own counted waits stay conservative.
+// (s_nop: one wait state between an SALU write of M0 and an LDS-DMA that reads it.)
+__device__ __forceinline__ void bb_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, int voff)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");  // (M0 is a reserved register: the compiler sets it itself right before each of ITS
+                                                                               //  uses -- none in this kernel -- and keeps nothing in it)
+}
 
 // ZQ (round 5): the sinogram is the PRIVATE residual layout [z/4][angle][u][4] that tomo_fp3d_residual leaves on a context
-// set to TOMO_RESIDUAL_ZQUAD: a staging item is ONE 16-byte load (whole 640-byte runs per angle and quad) instead of four
-// dword gathers from rows nz * na * nu floats apart; the tile in LDS, the sampling and the epilogue are unchanged.
+// set to TOMO_RESIDUAL_ZQUAD: a staging item is ONE 16-byte word (whole 624-byte runs per angle and quad) instead of four
+// dword gathers from rows nz * na * nu floats apart, and since an item is one word and the tile is lane-linear in the item
+// index it goes from memory STRAIGHT INTO LDS (`buffer_load_dwordx4 ... lds`): no staging registers, no ds_write_b128 (13 clk
+// each on the VGPR -> LDS path), the descriptor's range check zero-fills samples outside the detector, and the batch b+1 is
+// in flight while batch b is sampled exactly as before.  The sampling and the epilogue are unchanged.
 template <int EPI, bool LERP8, bool ZQ = false>
 __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
 {
-    __shared__ float4 tile2[2][BB_AB * BB_ZQ * BB_PITCH];  // double-buffered [angle][z-quad][u], 2 x 20 KiB
-    __shared__ int umin_s[3][BB_AB];  // three slots: a slow wave may still sample batch b-1 while batch b+1's window is written
+    constexpr int BB_PITCH = bb_pitch<ZQ>, BB_ITEMS = bb_items<ZQ>, BB_NITEMS = bb_nitems<ZQ>;
+    // ONE __shared__ object: with a second one, however small, hipcc waits vmcnt(0) before the ds_reads of every angle while
+    // an LDS-DMA is in flight (cdna_hip_programming.md, ".s-level traps"), i.e. the staging of batch b+1 would be drained before
+    // batch b is sampled.  Layout: the double-buffered tile [2][angle][z-quad][u] (2 x 20 KiB), then the window table.
+    // ... and, for the same reason, the angle records of a batch ((cos, sin, detector offset) per angle; ZQ only): read from
+    // global memory inside the sampling loop they are ordinary VGPR-destination loads, and beside an LDS-DMA hipcc waits vmcnt(0)
+    // for those.  The thread that computes an angle's window leaves the record in LDS, the sampling reads it from there.
+    __shared__ float4 bb_smem[2 * BB_NITEMS + (3 * BB_AB * 4 + 15) / 16 + (ZQ ? 3 * BB_AB : 0)];
+    float4(*tile2)[BB_NITEMS] = reinterpret_cast<float4(*)[BB_NITEMS]>(bb_smem);
+    // three slots: a slow wave may still sample batch b-1 while batch b+1's window is written
+    int(*umin_s)[BB_AB] = reinterpret_cast<int(*)[BB_AB]>(bb_smem + 2 * BB_NITEMS);
+    [[maybe_unused]] float4(*ang_s)[BB_AB] = reinterpret_cast<float4(*)[BB_AB]>(bb_smem + 2 * BB_NITEMS + (3 * BB_AB * 4 + 15) / 16);
 
     // XCD-aware numbering: workgroup b lands on XCD b%8; give each XCD its own z-brick stream
     const int ntiles = a.ntx * a.nty;
@@ -87,17 +119,31 @@ __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
             // clamp so that the int conversion and the offsets below stay in range whatever the geometry
             const float lo = fminf(fminf(f00, f10), fminf(f01, f11));
             umin_s[buf][tid] = (int)fminf(fmaxf(floorf(lo), -1.0e6f), 1.0e6f);
+            if constexpr (ZQ) ang_s[buf][tid] = make_float4(t.cs, t.sn, off, 0.0f);
         }
     };
 
-    float4 pre[BB_ITEMS];
-    auto prefetch = [&](int a0, int buf) {  // batch a0 -> registers (zero outside the detector)
-        const float *base = sino_z0 + (size_t)a0 * a.nu;
-        const int amax = a.na - 1 - a0;  // angle slots beyond the subset re-read the last angle (never sampled)
-        // ZQ: the quads of this z-brick from angle a0 on, as one buffer (host guarantees 4 * zstride * 16 < 2^31)
-        [[maybe_unused]] const __amdgpu_buffer_rsrc_t zq_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+    [[maybe_unused]] float4 pre[BB_ITEMS];  // planar staging only
+    const int wave_item0 = __builtin_amdgcn_readfirstlane(tid & ~63);  // first item of this wave in every item round
+    // ZQ: batch a0 -> LDS tile `dst` directly (one LDS-DMA per item, zero outside the detector)
+    auto dma = [&](int a0, int buf, float4 *dst) {
+        const int amax = a.na - 1 - a0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(reinterpret_cast<const float4 *>(sino_z0) + (size_t)a0 * a.nu), 0,
             (int)(((unsigned)min((zlim >> 2) + 1, BB_ZQ) * zstride - (unsigned)a0 * (unsigned)a.nu) << 4), 0x00020000);
+#pragma unroll
+        for (int m = 0; m < BB_ITEMS; ++m) {
+            const int u = umin_s[buf][it_aa[m]] + it_j[m];
+            unsigned off = it_off[m] + (unsigned)min(max(u, 0), a.nu - 1);
+            if (it_aa[m] > amax) off -= (unsigned)(it_aa[m] - amax) * (unsigned)a.nu;
+            const int boff = (u >= 0 && u < a.nu) ? (int)(off << 4) : (int)0x80000000;
+            if (256 * (m + 1) <= BB_NITEMS || tid + 256 * m < BB_NITEMS)  // (the last round is partial)
+                bb_dma16(rs, (unsigned)(uintptr_t)(bb_lds_ptr)(dst + wave_item0 + 256 * m), boff);
+        }
+    };
+    auto prefetch = [&](int a0, int buf) {  // planar: batch a0 -> registers (zero outside the detector)
+        const float *base = sino_z0 + (size_t)a0 * a.nu;
+        const int amax = a.na - 1 - a0;  // angle slots beyond the subset re-read the last angle (never sampled)
 #pragma unroll
         for (int m = 0; m < BB_ITEMS; ++m) {
             const int u = umin_s[buf][it_aa[m]] + it_j[m];
@@ -105,15 +151,7 @@ __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
             unsigned off = it_off[m] + (unsigned)min(max(u, 0), a.nu - 1);
             if (it_aa[m] > amax) off -= (unsigned)(it_aa[m] - amax) * (unsigned)a.nu;
             float4 v;
-            if constexpr (ZQ) {
-                // one 16-byte buffer load; a sample outside the detector gets an out-of-range offset and reads as zero (the
-                // descriptor's range check replaces the four masks).  Slices past the end of the volume were written as
-                // zeros by the producer; quads past it re-read the last one and feed accumulators that are never stored.
-                const int boff = mk ? (int)(off << 4) : (int)0x80000000;
-                const v4f q = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(zq_rsrc, boff, 0, 0));
-                pre[m] = make_float4(q.x, q.y, q.z, q.w);
-                continue;
-            } else if (!ragged) {
+            if (!ragged) {
                 v.x = base[off];
                 v.y = base[off + zstride];
                 v.z = base[off + 2 * zstride];
@@ -135,7 +173,8 @@ __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
 
     window(0, 0);
     __syncthreads();
-    prefetch(0, 0);
+    if constexpr (ZQ) dma(0, 0, tile2[0]);
+    else prefetch(0, 0);
     int buf = 0;
     for (int a0 = 0; a0 < a.na; a0 += BB_AB, buf = (buf == 2 ? 0 : buf + 1)) {
         const int nb = min(BB_AB, a.na - a0);
@@ -144,20 +183,33 @@ __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
         if (more) window(a0 + BB_AB, nbuf);
         // double-buffered tile: waves still sampling batch b-1 read the other buffer, so one barrier per batch is enough
         float4 *tile = tile2[(a0 / BB_AB) & 1];
+        if constexpr (ZQ) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's pieces of tile b have landed in LDS
+        } else {
 #pragma unroll
-        for (int m = 0; m < BB_ITEMS; ++m) tile[tid + 256 * m] = pre[m];
+            for (int m = 0; m < BB_ITEMS; ++m) tile[tid + 256 * m] = pre[m];
+        }
         __syncthreads();  // tile b and the window of batch b+1 visible; everyone is past the sampling of batch b-1
-        if (more) prefetch(a0 + BB_AB, nbuf);  // in flight while this batch is sampled
+        if (more) {       // in flight while this batch is sampled
+            if constexpr (ZQ) dma(a0 + BB_AB, nbuf, tile2[((a0 / BB_AB) + 1) & 1]);
+            else prefetch(a0 + BB_AB, nbuf);
+        }
         auto sample = [&](int aa) {
-            const tomo_angle_t t = a.tab[a0 + aa];
-            const float off = half_u - t.cor;
+            float t_cs, t_sn, off;
+            if constexpr (ZQ) {
+                const float4 an = ang_s[buf][aa];
+                t_cs = an.x; t_sn = an.y; off = an.z;
+            } else {
+                const tomo_angle_t t = a.tab[a0 + aa];
+                t_cs = t.cs; t_sn = t.sn; off = half_u - t.cor;
+            }
             // the window origin is wave-uniform: fold it into a scalar byte offset so that a tap address is one v_lshl_add
             int ab = __builtin_amdgcn_readfirstlane((aa * (BB_ZQ * BB_PITCH) - umin_s[buf][aa]) * 16);
             asm("" : "+s"(ab));  // opaque: otherwise the *16 is factored back out (a second VALU op per tap)
             const char *tb = reinterpret_cast<const char *>(tile);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const float f = fmaf(xw, t.cs, fmaf(r ? yw1 : yw0, t.sn, off));
+                const float f = fmaf(xw, t_cs, fmaf(r ? yw1 : yw0, t_sn, off));
                 const float fl = floorf(f);
                 const float w = lerp_w<LERP8>(f, fl), omw = 1.0f - w;
                 const int idx = (int)fl;
