@@ -66,7 +66,7 @@ def make_pair(oracle, g, flags=0):
 
 
 @pytest.mark.parametrize("g", GEOMS)
-@pytest.mark.parametrize("variant", _v(0, 1, 2))
+@pytest.mark.parametrize("variant", _v(0, 1, 2, 3))   # 0 re-lays the planar sinogram quad-interleaved (LDS-DMA staging); 3 = planar staging
 def test_backprojection_vs_oracle(oracle, ops, g, variant):
     P, H = make_pair(oracle, g)
     ops.set_variant("bp", variant)
@@ -165,7 +165,7 @@ def test_forward_projection_dense_angle_form_random_geometries(oracle, ops, seed
     print("dense form taken:", took, (nz, n, nu, na, os_n))
 
 
-@pytest.mark.parametrize("bp_variants", [(0,), pytest.param((1, 2), marks=DEV)])
+@pytest.mark.parametrize("bp_variants", [(0,), pytest.param((1, 2, 3), marks=DEV)])
 def test_lerp8_mode_and_reference_literals(oracle, ops, bp_variants):
     """tests/test_RecToolsDIRCuPy.py:671-694 of the reference: ones(128,160,160) -> min 67.27458 max 225.27428."""
     from tomobar_amd.projector import HipTools3D
@@ -196,7 +196,7 @@ def test_power_method_literals(oracle):
                                # 3 x 6 x 2 whole 32x16x16 bricks (epilogue through LDS in dwordx4 row segments) next to
                                # ragged ones in x, y and z (direct stores) in the same launch
                                (37, 104, 96, 21, -0.75, 3)])
-@pytest.mark.parametrize("bp_variants", [(0,), pytest.param((1, 2), marks=DEV)])
+@pytest.mark.parametrize("bp_variants", [(0,), pytest.param((1, 2, 3), marks=DEV)])
 def test_fused_residual_and_gradient_steps(oracle, ops, g, bp_variants):
     P, H = make_pair(oracle, g)
     rng = np.random.default_rng(3)
@@ -536,7 +536,7 @@ def test_pad_crop_mask_permute(oracle, ops):
         assert np.array_equal(host(ops.contiguous(t.permute(*perm))), np.ascontiguousarray(host(t).transpose(perm)))
 
 
-@pytest.mark.parametrize("variants", [(0,), pytest.param((2, 1), marks=DEV)])
+@pytest.mark.parametrize("variants", [(0,), pytest.param((2, 1, 3), marks=DEV)])
 @pytest.mark.parametrize("seed", range(24))
 def test_projector_pair_random_geometries(oracle, ops, seed, variants):
     """seeded random geometries (sizes that are not multiples of any tile, detector wider / narrower than the grid,

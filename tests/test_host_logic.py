@@ -34,7 +34,7 @@ def test_shipped_library_carries_no_ab_variants_or_probes():
     assert _lib.flavour() == "shipped"
     ship = _lib.lib()
     assert ship.tomo_build_flavour() == b"shipped"
-    for name, good, bad in (("bp", (0,), (1, 2, 7)), ("fp", (0,), (1, 2, 3)), ("pdtv", (0, 22), (1, 2, 3, 21, 31, 33)),
+    for name, good, bad in (("bp", (0,), (1, 2, 3, 7)), ("fp", (0,), (1, 2, 3)), ("pdtv", (0, 22), (1, 2, 3, 21, 31, 33)),
                             ("roftv", (0,), (1, 2, 3, 4))):
         for v in bad:
             assert ship.tomo_set_variant(name.encode(), v) == _lib.E_INVALID, (name, v)
@@ -46,7 +46,7 @@ def test_shipped_library_carries_no_ab_variants_or_probes():
     with _lib.use_flavour("dev") as dev:
         assert _lib.flavour() == "dev" and dev is _lib.lib() and dev is not ship
         assert dev.tomo_build_flavour() == b"dev"
-        for name, vs in (("bp", (1, 2)), ("fp", (1, 2, 3)), ("pdtv", (1, 2, 3, 21, 22, 31, 32)), ("roftv", (1, 2, 3, 4)), ("probe", (1, 0))):
+        for name, vs in (("bp", (1, 2, 3)), ("fp", (1, 2, 3)), ("pdtv", (1, 2, 3, 21, 22, 31, 32)), ("roftv", (1, 2, 3, 4)), ("probe", (1, 0))):
             for v in vs:
                 assert dev.tomo_set_variant(name.encode(), v) == _lib.OK, (name, v)
             dev.tomo_set_variant(name.encode(), 0)

@@ -289,6 +289,24 @@ __global__ __launch_bounds__(256) void bp_tiled_kernel(BpArgs a)
 
 #include "bp_brick.inl"
 
+// planar sinogram [nz][row] (row = na * nu) -> the quad-interleaved layout [ceil(nz/4)][row][4] the brick kernel stages by
+// LDS-DMA; slices past nz are zeros.  One coalesced pass: 8 B per sample moved, ~0.13 ms for a 75-angle subset at 1024^3.
+__global__ __launch_bounds__(256) void sino_to_quad_kernel(const float *__restrict__ in, float4 *__restrict__ out, int nz, size_t row)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int z = 4 * (int)blockIdx.y;
+    if (i >= row) return;
+    const float *p = in + (size_t)z * row + i;
+    float4 v;
+    v.x = p[0];
+    v.y = z + 1 < nz ? p[row] : 0.0f;
+    v.z = z + 2 < nz ? p[2 * row] : 0.0f;
+    v.w = z + 3 < nz ? p[3 * row] : 0.0f;
+    out[(size_t)blockIdx.y * row + i] = v;
+}
+
+constexpr size_t BP_RELAY_MAX_BYTES = (size_t)16 << 30;  // largest sinogram tomo_bp3d* re-lays into its scratch arena
+
 template <int EPI>
 int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
 {
@@ -304,32 +322,49 @@ int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
     // the brick kernel addresses a 16-slice sinogram slab with 32-bit element offsets
     // (the quad layout is read through one buffer descriptor per z-brick and batch: 4 quads x 16 bytes < 2^31)
     if (EPI == EPI_PLAIN) a.zquad = 0;  // tomo_bp3d always takes the public layout
-    const bool brick_ok = (long)a.na * a.nu < (a.zquad ? (1L << 25) : (1L << 27));
     if (a.zquad && (((uintptr_t)a.sino) & 15) != 0)
         return tomo_fail(TOMO_E_INVALID, "the quad-interleaved residual must be 16-byte aligned");
-    if (g_variant_bp == 1 || (g_variant_bp == 0 && !brick_ok)) {
-        if (g_variant_bp == 0)
+    // A PLANAR sinogram (tomo_bp3d: FBP, SIRT, CGLS, OSEM, the power method; the fused epilogues of the ring-term and
+    // vertical-CoR paths) is re-laid quad-interleaved into this stream's scratch arena first: one streaming pass (8 B per
+    // sample) buys the LDS-DMA staging of the brick kernel -- 4 workgroups per CU, no staging registers -- which is worth 7 x
+    // as much per 75-angle subset and 8 x for a whole angle set (docs/kernels/bp.md).  Not for sinograms beyond 16 GiB, not
+    // when the arena cannot be had (then the planar staging runs), and not with bp variant 3 (dev flavour: planar staging, A/B).
+    bool relaid = false;
+    if (g_variant_bp == 0 && !a.zquad && (long)a.na * a.nu < (1L << 25) && a.na > 0) {
+        const size_t row = (size_t)a.na * a.nu, nq = (size_t)ceil_div(a.nz, 4), bytes = nq * row * 16;
+        void *q = nullptr;
+        if (bytes <= BP_RELAY_MAX_BYTES && nq <= 65535 && tomo_arena_get(a.device, st, ARENA_BPQ, bytes, &q) == TOMO_OK) {
+            sino_to_quad_kernel<<<dim3((unsigned)((row + 255) / 256), (unsigned)nq), 256, 0, st>>>(a.sino, (float4 *)q, a.nz, row);
+            TOMO_LAUNCH_CHECK();
+            a.sino = (const float *)q;
+            a.zquad = 1;
+            relaid = true;
+        }
+    }
+    const bool brick_ok = (long)a.na * a.nu < (a.zquad ? (1L << 25) : (1L << 27));
+    const int variant = g_variant_bp == 3 ? 0 : g_variant_bp;  // 3 = the default kernel on the planar layout
+    if (variant == 1 || (variant == 0 && !brick_ok)) {
+        if (variant == 0)
             tomo_warn_once("bp_direct", "back projection: angles x detector >= 2^27 samples per slice, falling back to "
                                         "the direct (no LDS) kernel (about 3.5x slower)");
         if (a.path) *a.path = "direct(no LDS)";
         dim3 grid(ceil_div(a.n, 64), ceil_div(a.n, 4), ceil_div(a.nz, 4));
         if (lerp8) bp_direct_kernel<EPI, true><<<grid, 256, 0, st>>>(a);
         else bp_direct_kernel<EPI, false><<<grid, 256, 0, st>>>(a);
-    } else if (g_variant_bp == 0) {
+    } else if (variant == 0) {
         if (a.path) *a.path = "brick(32x16x16)";
         a.ntx = ceil_div(a.n, BB_TX);
         a.nty = ceil_div(a.n, BB_TY);
         a.nzb = ceil_div(a.nz, 4 * BB_ZQ);
         const long blocks = 8L * (((long)a.nzb * a.ntx * a.nty + 7) / 8);
         if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one BP launch");
-        if constexpr (EPI != EPI_PLAIN) {
-            if (a.zquad) {
-                if (a.path) *a.path = "brick(32x16x16, quad-interleaved residual)";
-                if (lerp8) bp_brick_kernel<EPI, true, true><<<(unsigned)blocks, 256, 0, st>>>(a);
-                else bp_brick_kernel<EPI, false, true><<<(unsigned)blocks, 256, 0, st>>>(a);
-                TOMO_LAUNCH_CHECK();
-                return TOMO_OK;
-            }
+        if (a.zquad) {
+            if (a.path) *a.path = relaid ? "brick(32x16x16, planar sinogram re-laid quad-interleaved, LDS-DMA staging)"
+                                         : "brick(32x16x16, quad-interleaved residual, LDS-DMA staging)";
+            if (lerp8) bp_brick_kernel<EPI, true, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+            else bp_brick_kernel<EPI, false, true><<<(unsigned)blocks, 256, 0, st>>>(a);
+            TOMO_LAUNCH_CHECK();
+            return TOMO_OK;
         }
         if (lerp8) bp_brick_kernel<EPI, true><<<(unsigned)blocks, 256, 0, st>>>(a);
         else bp_brick_kernel<EPI, false><<<(unsigned)blocks, 256, 0, st>>>(a);

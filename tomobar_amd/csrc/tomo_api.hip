@@ -60,7 +60,7 @@ extern "C" int tomo_set_variant(const char *kernel, int variant)
     };
     int *slot = nullptr;
     bool ok = false;
-    if (k == "bp") { slot = &g_variant_bp; ok = allowed({0}, {1, 2}); }
+    if (k == "bp") { slot = &g_variant_bp; ok = allowed({0}, {1, 2, 3}); }
     else if (k == "fp") { slot = &g_variant_fp; ok = allowed({0}, {1, 2, 3}); }
     else if (k == "pdtv") { slot = &g_variant_pdtv; ok = allowed({0, 22}, {1, 2, 3, 21, 31, 32}); }
     else if (k == "roftv") { slot = &g_variant_roftv; ok = allowed({0}, {1, 2, 3, 4}); }

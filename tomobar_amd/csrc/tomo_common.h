@@ -94,7 +94,7 @@ struct tomo_device_guard {
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 // grow-only scratch arena per (device, stream, slot) (tomo_release_scratch frees a device's arenas)
-enum { ARENA_MAIN = 0, ARENA_REDUCE = 1, ARENA_TV = 2 /* placed: the TV operators' work arrays */, ARENA_CALLER0 = 16 /* .. +7: tomo_placed_scratch (placed) */ };
+enum { ARENA_MAIN = 0, ARENA_REDUCE = 1, ARENA_TV = 2 /* placed: the TV operators' work arrays */, ARENA_BPQ = 3 /* a planar sinogram re-laid quad-interleaved for the back projector */, ARENA_CALLER0 = 16 /* .. +7: tomo_placed_scratch (placed) */ };
 int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void **out, bool place = false);  // place: see tomo_api.hip
 void tomo_fourier_cache_release(int device);  // cached hipFFT plans of fourier_inv.hip
 void tomo_fbp_cache_release(int device);      // cached hipFFT plans / filter tables of fbp_filter.hip
