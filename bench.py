@@ -374,6 +374,13 @@ def measure(args, env):
     if slab is not None:
         slab.timing = True
         rt.slab = slab
+    if args.reg != "none" and slab is None and os.environ.get("BENCH_RESERVE_LATE", "0") in ("", "0"):
+        # set-up, like the context and the sinogram: the library allocates and PLACES its TV scratch arena now (a search
+        # over up to eight candidate blocks, 0.1-6 s once per process; docs/kernels/placement.md) -- FIRST, while the device
+        # is still empty: the search can hold more candidates and sees unfragmented memory.  RecToolsIRCuPy does the same at
+        # the start of its first call (then a no-op here); done explicitly so that --warmup 0 does not time it
+        from tomobar_amd import ops as _ops0
+        _ops0.reserve_tv_scratch((nz, n, n), device, args.reg, args.half)
     # ---- synthetic data, resident in HBM: analytic line integrals of the ellipsoid phantom, transmission
     #      Poisson noise (I0 = 2e4 photons per pixel, peak attenuation 3), seed = rank
     sino = analytic_sinogram(n, nz_total, z0, nz, angles, device)
@@ -396,10 +403,7 @@ def measure(args, env):
                "time_marching_step": 1e-3, "half_precision": args.half}
 
     if reg is not None and slab is None:
-        # set-up, like the context and the sinogram: the library allocates and PLACES its TV scratch arena now (a search
-        # over up to eight candidate blocks, 0.1-4 s once per process; docs/kernels/placement.md).  RecToolsIRCuPy does the
-        # same at the start of its first call; done here explicitly so that --warmup 0 does not time it
-        _ops.reserve_tv_scratch((nz, n, n), device, args.reg, args.half)
+        _ops.reserve_tv_scratch((nz, n, n), device, args.reg, args.half)   # (a no-op unless BENCH_RESERVE_LATE=1 skipped the early one)
 
     def run(iters):
         d = {"projection_data": sino, "data_axes_labels_order": ["detY", "angles", "detX"]}

@@ -113,6 +113,29 @@ def test_use_flavour_is_per_thread():
         _lib.use_flavour("nightly")
 
 
+def test_committed_pmc_traffic_is_keyed_to_the_kernel_sources_at_head():
+    """profiles/pmc_traffic.json (what bench.py reports as roofline.traffic_committed) is only valid for the kernel sources the
+    counters were taken on: every entry carries the sha of those sources, and this test fails as soon as one of them differs
+    from the sources in the tree -- re-run `bash tools/run_pmc_refresh.sh <tag>` (or tools/run_full_set.sh) on the GPU and
+    commit the refreshed file together with the kernel change.  (Round 4's figure went stale silently.)"""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    stale = {}
+    for key, kern in (("pdtv", "pdtv"), ("pdtv_half", "pdtv"), ("roftv", "roftv"), ("bp", "bp"), ("fp", "fp")):
+        assert key in pmc, f"profiles/pmc_traffic.json has no entry for {key}"
+        ent = pmc[key]
+        assert ent["traffic_bytes"] > 0 and ent.get("profile", "").startswith("profiles/")
+        if ent["sources_sha16"] != bench.source_hash(kern):
+            stale[key] = (ent["sources_sha16"], bench.source_hash(kern))
+    assert not stale, f"stale PMC traffic entries (measured-on sha, current sha): {stale}"
+    # the evidence file an entry names must exist in the tree
+    for key in ("pdtv", "bp"):
+        assert os.path.exists(os.path.join(ROOT, pmc[key]["profile"])), pmc[key]["profile"]
+
+
 def test_no_gpu_means_loud_failure():
     """The product path has no CPU fallback: without a device every constructor raises."""
     if torch.cuda.is_available():

@@ -89,8 +89,21 @@ __device__ __forceinline__ void bp_epilogue(const BpArgs &a, size_t idx, float g
 template <int EPI>
 __device__ __forceinline__ void bp_epilogue4(const BpArgs &a, size_t idx, float4 g)
 {
+    // The epilogue's volume streams are touched once (X_t read, X written: 8.6 GB through a 4 MB L2 per 1024^3 call) while the
+    // sinogram windows of a z-brick (4.9 MB) are re-read by every brick of the XCD: with ordinary loads / stores the streams
+    // evict the windows and the L2 re-fetches them ~33 x from the fabric (14.6 GB per call); marked NON-TEMPORAL they leave the
+    // windows resident -- fetch 14.6 -> 4.9 GB (X_t + 1.8 x the subset), call 7.09 -> 6.90 ms (profiles/r5i_bp_epilogue_nontemporal_ab.txt).
+#ifndef TOMO_BP_EPI_TEMPORAL   // (A/B builds only: tools/run_ab.sh)
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    auto ld4 = [&](const float *p) {
+        const v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(p + idx));
+        return make_float4(t.x, t.y, t.z, t.w);
+    };
+    auto st4 = [&](float *p, float4 v) { __builtin_nontemporal_store(v4{v.x, v.y, v.z, v.w}, reinterpret_cast<v4 *>(p + idx)); };
+#else
     auto ld4 = [&](const float *p) { return *reinterpret_cast<const float4 *>(p + idx); };
     auto st4 = [&](float *p, float4 v) { *reinterpret_cast<float4 *>(p + idx) = v; };
+#endif
     const float gv[4] = {g.x, g.y, g.z, g.w};
     if (EPI == EPI_PLAIN) {
         st4(a.vol, g);

@@ -295,12 +295,17 @@ class RecToolsIRCuPy:
         A = self.Atools
         b = d["projection_data"]
         x = self._new_vol(0.0)
-        res = torch.empty_like(b)
         step = float32(a["tau_step_lanweber"])
-        for _ in range(a["iterations"]):
-            A.residual(x, b, None, "LS", None, res)
-            # x - tau*g with the clamp as a separate rounding step, like the reference's in-place ops
-            A.grad_step(res, x, x, step, a["nonnegativity"], None)
+        # the residual goes straight from the forward projector into the fused gradient step: quad-interleaved (see FISTA)
+        A.set_residual_layout("planar" if getattr(A, "has_vertical_shift", False) else "zquad")
+        try:
+            res = A.residual_buffer(None)
+            for _ in range(a["iterations"]):
+                A.residual(x, b, None, "LS", None, res)
+                # x - tau*g with the clamp as a separate rounding step, like the reference's in-place ops
+                A.grad_step(res, x, x, step, a["nonnegativity"], None)
+        finally:
+            A.set_residual_layout("planar")
         return self._finalise(x, a)
 
     def SIRT(self, _data_: dict, _algorithm_: Union[dict, None] = None) -> torch.Tensor:

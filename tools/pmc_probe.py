@@ -1,11 +1,11 @@
 """Small fixed workloads for rocprofv3 --pmc passes (one kernel class per invocation, few launches).
-usage: python tools/pmc_probe.py <what> [N] [NZ] [NA]   what in {pdtv0,pdtv1,pdtv0h,roftv,bp0,bp1,bpq,fp,fpq,momentum,fourier}"""
+usage: python tools/pmc_probe.py <what> [N] [NZ] [NA]   what in {pdtv0,pdtv1,pdtv0h,roftv,bp0,bp1,bp3,bpp,bpq,fp,fpq,momentum,fourier}"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-if os.environ.get("PMC_PROBE", "0") != "0" or (len(sys.argv) > 1 and sys.argv[1].rstrip("h") in ("pdtv1", "pdtv2", "pdtv21", "bp1", "bp2")):
+if os.environ.get("PMC_PROBE", "0") != "0" or (len(sys.argv) > 1 and sys.argv[1].rstrip("h") in ("pdtv1", "pdtv2", "pdtv21", "bp1", "bp2", "bp3", "bpp")):
     os.environ.setdefault("TOMO_MI355X_FLAVOUR", "dev")   # measurement switches / A-B variants: libtomo_mi355x_dev.so
 from tomobar_amd import ops
 from tomobar_amd.projector import HipTools3D
@@ -46,7 +46,13 @@ elif what == "momentum":
 else:
     H = HipTools3D(N, 0, NZ, np.linspace(0, np.pi, NA, endpoint=False), 0.0, N, "gpu", 0, None)
     sino = torch.rand((NZ, NA, N), device="cuda")
-    if what in ("bpq", "fpq"):   # the fused pair as the FISTA loop runs it: residual in the quad-interleaved layout (round 5)
+    if what == "bpp":   # the fused gradient step on the PLANAR residual with planar staging (bp variant 3, dev flavour): the round-4 path
+        ops.set_variant("bp", 3)
+        res = H.residual_buffer(None)
+        H.residual(vol, sino, None, "LS", None, res)
+        for _ in range(3):
+            H.grad_step(res, vol, out, 1e-4, True, None)
+    elif what in ("bpq", "fpq"):   # the fused pair as the FISTA loop runs it: residual in the quad-interleaved layout (round 5)
         H.set_residual_layout("zquad")
         res = H.residual_buffer(None)
         for _ in range(2 if what == "fpq" else 1):
