@@ -21,6 +21,7 @@
 #include "tomo_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <string>
 #include <type_traits>
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(256) void sino_to_quad_kernel(const float *__restri
 }
 
 constexpr size_t BP_RELAY_MAX_BYTES = (size_t)16 << 30;  // largest sinogram tomo_bp3d* re-lays into its scratch arena
+std::atomic<size_t> g_bp_relay_refused{~(size_t)0};      // smallest relay scratch the device could NOT provide (never asked again)
 
 template <int EPI>
 int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
@@ -346,7 +348,12 @@ int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
     if (g_variant_bp == 0 && !a.zquad && (long)a.na * a.nu < (1L << 25) && a.na > 0) {
         const size_t row = (size_t)a.na * a.nu, nq = (size_t)ceil_div(a.nz, 4), bytes = nq * row * 16;
         void *q = nullptr;
-        if (bytes <= BP_RELAY_MAX_BYTES && nq <= 65535 && tomo_arena_get(a.device, st, ARENA_BPQ, bytes, &q) == TOMO_OK) {
+        bool have = bytes <= BP_RELAY_MAX_BYTES && nq <= 65535 && bytes < g_bp_relay_refused.load();
+        if (have && tomo_arena_get(a.device, st, ARENA_BPQ, bytes, &q) != TOMO_OK) {
+            g_bp_relay_refused.store(bytes);   // out of memory: the planar staging runs, now and for every request this large
+            have = false;
+        }
+        if (have) {
             sino_to_quad_kernel<<<dim3((unsigned)((row + 255) / 256), (unsigned)nq), 256, 0, st>>>(a.sino, (float4 *)q, a.nz, row);
             TOMO_LAUNCH_CHECK();
             a.sino = (const float *)q;

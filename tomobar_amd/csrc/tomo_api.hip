@@ -366,14 +366,14 @@ double place_score(void *p, size_t bytes, hipStream_t st)
 
 // plain allocation; a first failure is retried a few times: another process sharing the GPU may be holding placement
 // candidates for a fraction of a second (ranks that share a device in the functional multi-process tests)
-int patient_malloc(size_t bytes, void **out)
+int patient_malloc(size_t bytes, void **out, int attempts = 4)
 {
     hipError_t e = hipSuccess;
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    for (int attempt = 0; attempt < attempts; ++attempt) {
         e = hipMalloc(out, bytes);
         if (e == hipSuccess) return TOMO_OK;
         (void)hipGetLastError();
-        if (e != hipErrorOutOfMemory) break;
+        if (e != hipErrorOutOfMemory || attempt + 1 == attempts) break;
         struct timespec ts = {0, 300 * 1000 * 1000};
         nanosleep(&ts, nullptr);
     }
@@ -473,7 +473,8 @@ int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void 
         TOMO_HIP(hipFree(old));
     }
     void *p = nullptr;
-    const int rc = place ? placed_malloc(stream, bytes, &p) : patient_malloc(bytes, &p);
+    // (the back projector's relay scratch is an optimisation it can do without: one attempt, no waiting)
+    const int rc = place ? placed_malloc(stream, bytes, &p) : patient_malloc(bytes, &p, slot == ARENA_BPQ ? 1 : 4);
     if (rc != TOMO_OK) return rc;
     std::lock_guard<std::mutex> lk(g_arena_mu);
     arena_t &a = g_arenas[arena_key{device, stream, slot}];
