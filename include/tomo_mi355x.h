@@ -95,7 +95,12 @@ const char *tomo_ctx_kernel_path(const tomo_ctx *ctx, const char *op);
  *            reached through AstraTools3D._forwprojCuPy/_forwprojOSCuPy (astra_tools3d.py:78-86).
  * tomo_bp3d  replaces AstraBase.runAstraBackproj3DCuPy (astra_base.py:518-558, direct_BP3D :554)
  *            reached through _backprojCuPy/_backprojOSCuPy (astra_tools3d.py:102-110).
- * sino_dev is [nz][subset_size][nu]; both outputs are fully overwritten. */
+ * sino_dev is [nz][subset_size][nu]; both outputs are fully overwritten.
+ * Scratch: tomo_fp3d* keeps an in-plane transposed copy of the volume in the context (nz*n*n floats, tomo_ctx_release_scratch);
+ * tomo_bp3d* (every form, fused epilogues included) re-lays a PLANAR sinogram quad-interleaved -- one streaming pass -- into a
+ * scratch arena of this (device, stream) that is as large as the sinogram (4*ceil(nz/4)*subset_size*nu floats, grow-only, freed
+ * by tomo_release_scratch): its kernel stages that layout by LDS-DMA, which is worth 7-8 x the pass.  Sinograms beyond 16 GiB,
+ * or a device that cannot provide the arena (remembered, never asked again), take the planar staging instead: slower, same bits. */
 int tomo_fp3d(tomo_ctx *ctx, int subset, const float *vol_dev, float *sino_dev, void *stream);
 int tomo_bp3d(tomo_ctx *ctx, int subset, const float *sino_dev, float *vol_dev, void *stream);
 
