@@ -32,7 +32,7 @@ int main()
     hipEventCreate(&e0); hipEventCreate(&e1);
     const size_t bytes = (size_t)34360297472ull;
     std::vector<char *> blocks;
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 5; ++k) {
         char *p;
         size_t fr, tot; hipMemGetInfo(&fr, &tot);
         if (fr < bytes + ((size_t)4 << 30) || hipMalloc(&p, bytes) != hipSuccess) break;
@@ -40,8 +40,10 @@ int main()
     }
     printf("%zu blocks of %.1f GB held\n", blocks.size(), bytes / 1e9);
     const size_t plane = (size_t)1 << 20;  // floats
-    const size_t pads[] = {0, 256, 1024, 2048, 4096 + 256, 16384, 17472, 65536 + 1024, 262144};
-    for (int rep = 0; rep < 2; ++rep)
+    // pads in floats (x 4 = bytes)
+    const size_t pads[] = {0, 17472 /*0x11100 B*/, 0x1100 / 4, 0x10100 / 4, 0x11000 / 4, 0x100 / 4, 0x8880 / 4, 0x22200 / 4, 0x33300 / 4, 0x111100 / 4,
+                           0x1111100 / 4, 0x5500 / 4, 0x15500 / 4, 0x10000 / 4, 0x30300 / 4, 0x11300 / 4, 0x13100 / 4, 0x7700 / 4, 0x1f00 / 4, 0x11111100 / 4};
+    for (int rep = 0; rep < 1; ++rep)
         for (size_t k = 0; k < blocks.size(); ++k) {
             printf("block %zu:", k);
             for (size_t pad : pads) {
@@ -59,7 +61,7 @@ int main()
                     float ms; hipEventElapsedTime(&ms, e0, e1);
                     best = std::max(best, (float)(2.0 * nz * 4194304.0 / ms / 1e6));
                 }
-                printf("  +%zu B: %6.0f", pad * 4, best);
+                printf("  +0x%zx: %4.0f", pad * 4, best);
             }
             printf("  GB/s\n");
             fflush(stdout);
