@@ -360,3 +360,28 @@ def test_fista_repeated_calls_on_one_object_are_bit_identical(oracle, geom, meth
     A.forward(xo, 0)                             # another volume's projection spends the token too
     xt.mul_(2.0)
     assert np.array_equal(host(A.forward(xt, 1)), 2.0 * ref)
+
+
+def test_reserve_scratch_is_an_optional_set_up_step(oracle):
+    """RecToolsIRCuPy.reserve_scratch (no reference counterpart): allocates / places the TV arena ahead of the first call.  It
+    changes no result, tolerates every regulariser dictionary the drivers accept (None, no method, 2D geometry, binary16
+    duals, ROF_TV) and a second call is a no-op; the drivers make the same reservation themselves."""
+    import ctypes as C
+    from tomobar_amd import _lib
+    from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy
+    nz, n, na = 6, 40, 24
+    angles = np.linspace(0, np.pi, na, endpoint=False)
+    sino = torch.rand((nz, na, n), device="cuda")
+    data = {"projection_data": sino, "data_axes_labels_order": ["detY", "angles", "detX"]}
+    algo = {"iterations": 2, "lipschitz_const": 2000.0}
+    reg = {"method": "PD_TV", "regul_param": 1e-3, "iterations": 6}
+    a = RecToolsIRCuPy(n, 0, nz, 0.0, angles, n, 0, None)
+    want = a.FISTA(dict(data), dict(algo), dict(reg))
+    _lib.check(_lib.lib().tomo_release_scratch(0))
+    b = RecToolsIRCuPy(n, 0, nz, 0.0, angles, n, 0, None)
+    for r in (None, {}, {"method": None}, dict(reg), dict(reg), dict(reg, half_precision=True), {"method": "ROF_TV"}):
+        b.reserve_scratch(r)
+    assert torch.equal(b.FISTA(dict(data), dict(algo), dict(reg)), want)
+    flat = RecToolsIRCuPy(n, 0, None, 0.0, angles, n, 0, None)       # 2D geometry: the arena of the 2D kernels
+    flat.reserve_scratch(dict(reg))
+    assert flat.FISTA({"projection_data": sino[0], "data_axes_labels_order": ["angles", "detX"]}, dict(algo), dict(reg)).shape == (1, n, n)

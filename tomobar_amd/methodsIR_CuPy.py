@@ -77,6 +77,15 @@ class RecToolsIRCuPy:
     def objsize_user_given(self, value):
         self._objsize_user_given = value
 
+    def reserve_scratch(self, _regularisation_: Union[dict, None]) -> None:
+        """Optional set-up call (no reference counterpart): allocate and PLACE the TV operators' scratch arena for this
+        geometry now.  ``FISTA`` / ``ADMM`` / ``OSEM`` do it themselves at the start of their first call; calling it right
+        after the constructor -- before the projection data are moved to the GPU -- lets the placement search see an
+        empty device, where it ends on a block of the fast class in 5 of 5 processes instead of 2 of 5
+        (docs/kernels/placement.md, profiles/r5f_bench_reserve_order_ab.txt).  A later call is a no-op."""
+        if _regularisation_ is not None and _regularisation_.get("method") is not None:
+            reserve_prox_scratch(self, self.Atools.vol_shape(), _regularisation_)
+
     # ------------------------------------------------------------------ operators
     def _Ax(self, x, sub_ind: int = 1, os: bool = False):
         return self.Atools._forwprojOSCuPy(x, os_index=sub_ind) if os else self.Atools._forwprojCuPy(x)
