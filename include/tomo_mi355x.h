@@ -142,7 +142,8 @@ int tomo_ring_gh_update(float *r_dev, float *r_old_dev, float *rx_dev, float lam
  * CenterRotOffset may be [angles, 2] = (horizontal, vertical) offsets (supp/funcs.py:52-55).  The context takes the
  * horizontal components; a vertical component moves the detector of angle a by shift[a] rows, which for parallel rays is a
  * per-angle 2-tap resampling of the detector rows (zero outside): A_v = R(+shift) A, A_v^T = A^T R(-shift).
- * tomo_shift_rows: out[r,a,:] = (1-w) in[r0,a,:] + w in[r0+1,a,:], r0 = floor(r + sign*shift[a]) (shift_dev: float32 [na]).
+ * tomo_shift_rows: out[r,a,:] = (1-w) in[r+k,a,:] + w in[r+k+1,a,:], k + w = sign*shift[a], k = floor (shift_dev: float32 [na];
+ * the weight does not depend on the row, so a z-slab with ghost rows resamples exactly as the whole detector does).
  * tomo_sino_residual: the residual of data_fidelities.py:28-39 on an already projected subset (the fused
  * tomo_fp3d_residual cannot resample between projector and residual; ``gathered`` as there).  Not used when no vertical component is given. */
 int tomo_shift_rows(const float *in_dev, float *out_dev, int nz, int na, int nu, const float *shift_dev, float sign,

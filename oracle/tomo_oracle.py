@@ -175,17 +175,18 @@ class Projector:
         return self.full if subset is None else self.tables[subset]
 
     def shift_rows(self, sino, subset, sign):
-        """out[r, a, :] = (1 - w) sino[r0, a, :] + w sino[r0 + 1, a, :], r0 + w = r + sign * vshift[a]; rows outside the
-        detector read as zero.  float32 throughout, one rounding per operation."""
+        """out[r, a, :] = (1 - w) sino[r + k, a, :] + w sino[r + k + 1, a, :], k + w = sign * vshift[a] (k = floor): the
+        weight is the fractional part of the shift alone, the same for every row, so that a z-slab of the detector rows
+        (tomobar_amd.slab) resamples exactly as the whole detector does; rows outside the detector read as zero.
+        float32 throughout, one rounding per operation."""
         idx = np.arange(self.na) if subset is None else self.subsets[subset]
         sh = self.vshift[idx] * np.float32(sign)
         out = np.zeros_like(sino)
-        r = np.arange(self.nz, dtype=np.float32)
+        r = np.arange(self.nz, dtype=np.int64)
         for a in range(sino.shape[1]):
-            f = r + sh[a]
-            fl = np.floor(f)
-            w = (f - fl).astype(np.float32)[:, None]
-            r0 = fl.astype(np.int64)
+            fl = np.floor(sh[a])
+            w = np.float32(sh[a] - fl)
+            r0 = r + int(fl)
             s0 = np.where(((r0 >= 0) & (r0 < self.nz))[:, None], sino[np.clip(r0, 0, self.nz - 1), a, :], np.float32(0))
             s1 = np.where(((r0 + 1 >= 0) & (r0 + 1 < self.nz))[:, None], sino[np.clip(r0 + 1, 0, self.nz - 1), a, :],
                           np.float32(0))

@@ -35,6 +35,44 @@ class OracleTools3D:
         self.na = self.P.na
         self._device = torch.device("cpu")
         self.vol_geom = {"GridRowCount": self.n, "GridColCount": self.n, "GridSliceCount": self.nz}
+        self.slab = None   # set through RecToolsIRCuPy.slab, as on HipTools3D
+
+    # -- the oracle's projector pair; with a vertical CoR component in z-slab mode the row resampling runs on the slab's rows
+    #    plus the neighbours' ghost rows, fetched by the PRODUCT's exchange (tomobar_amd.slab.extend_detector_rows), exactly
+    #    as HipTools3D._shift_rows does around the HIP kernels
+    def _shift(self, sino, sub, sign):
+        from tomobar_amd.slab import check_ghost_rows, extend_detector_rows
+        P = self.P
+        g = int(np.ceil(float(np.abs(P.vshift).max()))) + 1
+        if getattr(self, "_vshift_checked", None) is not self.slab:
+            check_ghost_rows(self.slab, g, self.nz, "a vertical CoR component")
+            self._vshift_checked = self.slab
+        ext, lo = extend_detector_rows(self.slab, torch.from_numpy(np.ascontiguousarray(sino)), g)
+        whole = types.SimpleNamespace(nz=int(ext.shape[0]), na=P.na, vshift=P.vshift, subsets=P.subsets)
+        return np.ascontiguousarray(O.Projector.shift_rows(whole, ext.numpy(), sub, sign)[lo:lo + self.nz])
+
+    def _sharded_shift(self):
+        return self.P.vshift is not None and self.slab is not None and self.slab.world > 1
+
+    def _fp(self, vol, sub):
+        if not self._sharded_shift():
+            return self.P.fp(vol, sub)
+        keep, self.P.vshift = self.P.vshift, None
+        try:
+            sino = self.P.fp(vol, sub)
+        finally:
+            self.P.vshift = keep
+        return self._shift(sino, sub, 1.0)
+
+    def _bp(self, sino, sub):
+        if not self._sharded_shift():
+            return self.P.bp(sino, sub)
+        sino = self._shift(sino, sub, -1.0)
+        keep, self.P.vshift = self.P.vshift, None
+        try:
+            return self.P.bp(sino, sub)
+        finally:
+            self.P.vshift = keep
 
     def _idx(self, os_index):
         return slice(None) if (os_index is None or self.ordsub_number == 1) else self.P.subsets[os_index]
@@ -58,15 +96,15 @@ class OracleTools3D:
         return torch.empty(self.sino_shape(os_index), dtype=torch.float32)
 
     def forward(self, vol, os_index=None, out=None):
-        r = self.P.fp(np.ascontiguousarray(_np(vol)), self._sub(os_index))
+        r = self._fp(np.ascontiguousarray(_np(vol)), self._sub(os_index))
         return torch.from_numpy(r) if out is None else _put(out, r)
 
     def backward(self, sino, os_index=None, out=None):
-        r = self.P.bp(np.ascontiguousarray(_np(sino)), self._sub(os_index))
+        r = self._bp(np.ascontiguousarray(_np(sino)), self._sub(os_index))
         return torch.from_numpy(r) if out is None else _put(out, r)
 
     def residual(self, vol, b, w, fidelity, os_index, out, gathered=0):
-        ax = self.P.fp(np.ascontiguousarray(_np(vol)), self._sub(os_index))
+        ax = self._fp(np.ascontiguousarray(_np(vol)), self._sub(os_index))
         idx = self._idx(os_index)
         bs = _np(b)[:, idx, :]
         if fidelity in ("LS", "PWLS"):
@@ -86,13 +124,13 @@ class OracleTools3D:
         pass
 
     def grad_step(self, res, x_t, x_out, l_inv, nonneg, os_index):
-        x = _np(x_t) - np.float32(l_inv) * self.P.bp(np.ascontiguousarray(_np(res)), self._sub(os_index))
+        x = _np(x_t) - np.float32(l_inv) * self._bp(np.ascontiguousarray(_np(res)), self._sub(os_index))
         if nonneg:
             np.maximum(x, 0, out=x)
         _put(x_out, x)
 
     def grad_step_momentum(self, res, x_t, x_old_then_x, l_inv, beta, nonneg, os_index):
-        x = _np(x_t) - np.float32(l_inv) * self.P.bp(np.ascontiguousarray(_np(res)), self._sub(os_index))
+        x = _np(x_t) - np.float32(l_inv) * self._bp(np.ascontiguousarray(_np(res)), self._sub(os_index))
         if nonneg:
             np.maximum(x, 0, out=x)
         xt = x + np.float32(beta) * (x - _np(x_old_then_x))
@@ -100,7 +138,7 @@ class OracleTools3D:
         _put(x_t, xt)
 
     def admm_z_update(self, res, z, x, u, zu_out, tau, rho, relax_on, one_minus_alpha, alpha, nonneg, os_index):
-        g = self.P.bp(np.ascontiguousarray(_np(res)), self._sub(os_index))
+        g = self._bp(np.ascontiguousarray(_np(res)), self._sub(os_index))
         z0, xn, un = _np(z).copy(), _np(x), _np(u)
         ga = np.float32(rho) * (z0 - xn + un)
         zn = z0 - np.float32(tau) * (g + ga)

@@ -143,15 +143,26 @@ def _fista_worker(rank, world, port, case):
         angles = np.linspace(0, np.pi, na, endpoint=False)
         rng = np.random.default_rng(2)
         sino = np.abs(O.shepp_logan_sino(n, nz, n, angles) / n + 0.02 * rng.standard_normal((nz, na, n))).astype(np.float32)
-        P = O.Projector(nz, n, n, angles, 0.0, os_n)
+        cor = 0.0
+        if case.get("vshift"):   # per-angle (horizontal, vertical) offsets: detector rows are resampled ACROSS the slab boundary
+            cor = np.stack([np.linspace(-1.0, 1.5, na), case["vshift"] * np.cos(np.linspace(0.3, 2.9, na))], axis=1)
+        P = O.Projector(nz, n, n, angles, cor, os_n)
         z0, z1 = slab_bounds(nz, world, rank)
-        rt = RecToolsIRCuPy(n, 0, z1 - z0, 0.0, angles, n, 0, os_n if os_n > 1 else None)
+        rt = RecToolsIRCuPy(n, 0, z1 - z0, cor, angles, n, 0, os_n if os_n > 1 else None)
         rt.slab = SlabComm(rank, world)
         # power method: the eigenvector spans all slabs (norm all-reduced every iteration)
         rt.power_seed = 3
         L_slab = rt.powermethod({"projection_data": None})
         L_whole = O.power_method(P, rng.standard_normal((nz, n, n)).astype(np.float32))
-        np.testing.assert_allclose(L_slab, L_whole, rtol=1e-4)
+        starts = []   # the start vector the ranks drew, slab by slab: the same iteration on the whole volume
+        for r in range(world):
+            g = torch.Generator()
+            g.manual_seed(3)
+            a, b = slab_bounds(nz, world, r)
+            starts.append(torch.randn((b - a, n, n), dtype=torch.float32, generator=g).numpy())
+        np.testing.assert_allclose(L_slab, O.power_method(P, np.concatenate(starts, axis=0)), rtol=1e-4)
+        # (with a vertical component the slices are coupled: 15 iterations from ANOTHER start agree to a few per cent only)
+        np.testing.assert_allclose(L_slab, L_whole, rtol=5e-2 if case.get("vshift") else 1e-4)
         reg = dict(case["reg"])
         full_reg = {"regul_param": 0.001, "iterations": 150, "time_marching_step": 0.005, "PD_LipschitzConstant": 12.0,
                     "methodTV": 0, **reg}
@@ -174,10 +185,15 @@ FISTA_CASES = [
     dict(method="FISTA", nz=8, os=1, fid="LS", reg=dict(method="ROF_TV", regul_param=0.002, iterations=5,
                                                         time_marching_step=0.002)),
     dict(method="ADMM", nz=10, os=3, fid="LS", reg=dict(method="PD_TV", regul_param=0.004, iterations=6)),
+    # vertical CoR component: ghost detector rows travel with every projector call (tomobar_amd.slab.extend_detector_rows)
+    dict(method="FISTA", nz=11, os=3, fid="PWLS", vshift=1.7, reg=dict(method="PD_TV", regul_param=0.002, iterations=6)),
+    dict(method="ADMM", nz=9, os=1, fid="LS", vshift=0.6, reg=dict(method="ROF_TV", regul_param=0.002, iterations=4,
+                                                                    time_marching_step=0.002)),
 ]
 
 
-@pytest.mark.parametrize("case", FISTA_CASES, ids=lambda c: f"{c['method']}-os{c['os']}-{c['fid']}-{c['reg']['method']}")
+@pytest.mark.parametrize("case", FISTA_CASES, ids=lambda c: f"{c['method']}-os{c['os']}-{c['fid']}-{c['reg']['method']}"
+                         + ("-vertical-cor" if c.get("vshift") else ""))
 def test_slab_reconstruction_drivers_match_whole_volume(case):
     """world-2 gloo run of RecToolsIRCuPy.powermethod / FISTA / ADMM with ``rt.slab`` set: power-method all-reduce, PWLS
     maximum all-reduce and the slab proximal step together; the oracle stands in for the C-ABI library at the projector /
@@ -209,6 +225,18 @@ def _short_slab_worker(rank, world, port):
                 assert "fewer than" in str(e)
             else:
                 raise AssertionError(f"rank {rank}: a too-short slab must raise on all ranks")
+        # ghost DETECTOR rows of a vertical CoR component: rank 2 holds one row, its neighbour needs three
+        from tomobar_amd.slab import check_ghost_rows, extend_detector_rows
+        try:
+            check_ghost_rows(comm, 3, z1 - z0, "a vertical CoR component")
+        except ValueError as e:
+            assert "thinner" in str(e)
+        else:
+            raise AssertionError(f"rank {rank}: a too-thin slab must raise on all ranks")
+        ext, lo = extend_detector_rows(comm, torch.full((z1 - z0, 2, 3), float(rank + 1)), 1)
+        assert lo == (1 if rank > 0 else 0) and ext.shape[0] == (z1 - z0) + lo + (1 if rank < world - 1 else 0)
+        assert rank == 0 or float(ext[0, 0, 0]) == rank              # the lower neighbour's last row
+        assert rank == world - 1 or float(ext[-1, 0, 0]) == rank + 2  # the upper neighbour's first row
         dist.barrier()                                 # all ranks got here: no deadlock
     finally:
         dist.destroy_process_group()

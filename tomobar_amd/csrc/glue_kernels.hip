@@ -240,10 +240,10 @@ __global__ __launch_bounds__(256) void shift_rows_kernel(const float *__restrict
         const int u = (int)(i % nu);
         const int a = (int)((i / nu) % na);
         const int r = (int)(i / ((size_t)nu * na));
-        const float f = (float)r + sign * shift[a];
-        const float fl = floorf(f);
-        const float w = f - fl;
-        const int r0 = (int)fminf(fmaxf(fl, -2.0f), (float)nz);  // clamped: both taps are outside the detector there
+        const float sh = sign * shift[a];
+        const float fl = floorf(sh);
+        const float w = sh - fl;  // the fractional part of the shift alone: the same for every row, whatever row a z-slab starts at
+        const int r0 = (int)fminf(fmaxf((float)r + fl, -2.0f), (float)nz);  // clamped: both taps are outside the detector there
         const float s0 = (r0 >= 0 && r0 < nz) ? in[((size_t)r0 * na + a) * nu + u] : 0.0f;
         const float s1 = (r0 + 1 >= 0 && r0 + 1 < nz) ? in[((size_t)(r0 + 1) * na + a) * nu + u] : 0.0f;
         out[i] = (1.0f - w) * s0 + w * s1;

@@ -62,6 +62,15 @@ class RecToolsIRCuPy:
         self.slab = None        # tomobar_amd.slab.SlabComm when this object reconstructs one z-slab of a larger volume
 
     @property
+    def slab(self):
+        return self._slab
+
+    @slab.setter
+    def slab(self, comm):
+        self._slab = comm
+        self.Atools.slab = comm   # the projector exchanges ghost detector rows itself when a vertical CoR component is set
+
+    @property
     def OS_number(self) -> int:
         return self._OS_number
 
@@ -139,9 +148,6 @@ class RecToolsIRCuPy:
         if x0 is None:
             x0 = self._new_vol(1.0 if method_run == "OSEM" else 0.0)
         use_os = self.OS_number > 1
-        if self.slab is not None and getattr(self.Atools, "has_vertical_shift", False):
-            raise ValueError("a vertical CoR component couples the z-slabs (detector rows are resampled across slab "
-                             "boundaries): reconstruct unsharded, or shard with whole-volume replicas")
         w = ops.pwls_weights(d["projection_data"], self.slab) if _data_["data_fidelity"] in ["PWLS", "SWLS"] else None
         # the TV operators' scratch arena is allocated and placed here, at set-up, not inside the first proximal step
         reserve_prox_scratch(self, rec_dim, r)

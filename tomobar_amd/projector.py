@@ -93,6 +93,7 @@ class HipTools3D:
 
         self.nz, self.n = self.detectors_y, self.recon_size
         self._vshift = None
+        self.slab = None   # tomobar_amd.slab.SlabComm when this object projects ONE z-slab of a larger volume (RecToolsIRCuPy.slab sets it)
         self.nu = self.detectors_x + 2 * self.detectors_x_pad
         self.na = self.angles_vec.size
 
@@ -201,6 +202,24 @@ class HipTools3D:
             tabs[key] = torch.from_numpy(np.ascontiguousarray(self._vshift[idx])).to(self._device)
         if out is None:
             out = torch.empty_like(sino)
+        slab = self.slab
+        if slab is not None and slab.world > 1:
+            # z-slab mode (round 5): detector row r of angle a looks at slice r + shift[a], which may lie in the NEIGHBOUR's
+            # slab.  g = ceil(max |shift|) + 1 ghost rows per interior side travel with one packed exchange; the resampling
+            # then runs on the extended rows (zero beyond the global first / last row, like the whole-volume operator) and the
+            # local rows are kept.  Same arithmetic per sample as unsharded: bit-identical.
+            from .slab import check_ghost_rows, extend_detector_rows
+            g = int(np.ceil(float(np.abs(self._vshift).max()))) + 1
+            if getattr(self, "_vshift_checked", None) is not slab:           # once per communicator
+                check_ghost_rows(slab, g, self.nz, f"a vertical CoR component of up to {float(np.abs(self._vshift).max()):.2f} rows")
+                self._vshift_checked = slab
+            ext, lo = extend_detector_rows(slab, sino, g)
+            ext_out = torch.empty_like(ext)
+            with torch.cuda.device(self._device):
+                self._chk(self._lib.tomo_shift_rows(ops.ptr(ext), ops.ptr(ext_out), int(ext.shape[0]), int(sino.shape[1]), self.nu,
+                                                ops.ptr(tabs[key]), float(sign), ops.stream_ptr(sino)))
+            out.copy_(ext_out[lo:lo + self.nz])
+            return out
         with torch.cuda.device(self._device):
             self._chk(self._lib.tomo_shift_rows(ops.ptr(sino), ops.ptr(out), self.nz, int(sino.shape[1]), self.nu,
                                             ops.ptr(tabs[key]), float(sign), ops.stream_ptr(sino)))

@@ -235,6 +235,27 @@ class _Exchange:
         self.reqs, self.unpack, self.owned = [], [], []
 
 
+def check_ghost_rows(comm, g: int, rows: int, what: str):
+    """Every rank raises, or none: some slab holds fewer than the ``g`` rows its neighbour needs as ghosts."""
+    if comm.allreduce_max(1.0 if g > rows else 0.0) > 0.0:
+        raise ValueError(f"{what} needs {g} ghost rows per slab boundary: some z-slab is thinner than that")
+
+
+def extend_detector_rows(comm, sino: torch.Tensor, g: int):
+    """The slab's projections ``[rows, angles, detX]`` with ``g`` ghost detector rows of each existing neighbour attached
+    (one packed exchange): returns (extended array, index of the first local row in it).  Beyond the global first / last
+    row nothing is attached -- a resampling of the extended rows reads zero there exactly as on the whole detector.
+    Used by the vertical centre-of-rotation component, whose per-angle row resampling crosses slab boundaries
+    (`HipTools3D._shift_rows`)."""
+    rows = int(sino.shape[0])
+    lo, hi = (g if comm.has_lo else 0), (g if comm.has_hi else 0)
+    ext = torch.zeros((lo + rows + hi,) + tuple(sino.shape[1:]), dtype=sino.dtype, device=sino.device)
+    ext[lo:lo + rows] = sino
+    comm.exchange([sino[0:g]] if comm.has_lo else [], [ext[0:g]] if comm.has_lo else [],
+                  [sino[rows - g:rows]] if comm.has_hi else [], [ext[lo + rows:]] if comm.has_hi else [])
+    return ext, lo
+
+
 def _halo_staging_bytes(nbytes):
     """tomo_halo_staging_bytes: every block starts 16-byte aligned in the staging buffer."""
     return sum((int(b) + 15) // 16 * 16 for b in nbytes)
