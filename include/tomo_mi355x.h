@@ -150,6 +150,9 @@ int tomo_shift_rows(const float *in_dev, float *out_dev, int nz, int na, int nu,
                     void *stream);
 int tomo_sino_residual(const float *ax_dev, const float *b_full_dev, const float *w_full_dev, const int *src_dev, int nz,
                        int na_s, int na_full, int nu, int gathered, int fidelity, float *res_dev, void *stream);
+/* tomo_sino_add_ring: res[z,a,u] += ring_scale * ring[z,u] -- the Group-Huber offsets on a residual formed by
+ * tomo_sino_residual (the pair replaces tomo_fp3d_residual_ring when a vertical component sits between projector and residual). */
+int tomo_sino_add_ring(float *res_dev, const float *ring_dev, float ring_scale, int nz, int na_s, int nu, void *stream);
 
 /* tomo_bp3d_fista: x_out = P+( x_t - l_inv * A_s^T res )            methodsIR_CuPy.py:463-468
  *   nonneg != 0 applies the max(.,0) projection.  x_out may alias x_t. */

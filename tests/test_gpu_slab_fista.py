@@ -81,8 +81,11 @@ def _worker(rank, world, port, case, backend="gloo"):
                     "methodTV": 0, **reg}
         d = {"projection_data": torch.from_numpy(sino[z0:z1].copy()).to(dev),
              "data_axes_labels_order": ["detY", "angles", "detX"], "data_fidelity": case["fid"]}
+        ring = case.get("ring")
+        if ring:   # Group-Huber offsets [detY, detX]: slab-local, the angle sums never cross a slab boundary
+            d.update(ringGH_lambda=ring["lambda"], ringGH_accelerate=ring["accelerate"])
         if case["method"] == "FISTA":
-            want = O.fista(P, sino, 2, L_whole, True, full_reg, case["fid"])
+            want = O.fista(P, sino, 2, L_whole, True, full_reg, case["fid"], ring=ring)
             got = rt.FISTA(d, {"iterations": 2, "lipschitz_const": L_whole, "nonnegativity": True,
                                "recon_mask_radius": None}, reg)
         else:
@@ -94,7 +97,7 @@ def _worker(rank, world, port, case, backend="gloo"):
         assert np.array_equal(got, want[z0:z1]), (rank, float(np.abs(got - want[z0:z1]).max()))
         # ---- Lipschitz constant computed inside (power method + all-reduce) and used by FISTA: close to the oracle's run
         got2 = rt.FISTA(dict(d), {"iterations": 1, "nonnegativity": True, "recon_mask_radius": None}, reg)
-        want2 = O.fista(P, sino, 1, L_same, True, full_reg, case["fid"])
+        want2 = O.fista(P, sino, 1, L_same, True, full_reg, case["fid"], ring=ring)
         torch.cuda.synchronize()
         r = np.linalg.norm(got2.cpu().numpy() - want2[z0:z1]) / max(np.linalg.norm(want2[z0:z1]), 1e-30)
         assert r < 1e-3, r
@@ -111,10 +114,13 @@ CASES = [
     dict(method="FISTA", nz=13, os=3, fid="PWLS", vshift=1.7, reg=dict(method="PD_TV", regul_param=0.002, iterations=6)),
     dict(method="ADMM", nz=12, os=1, fid="LS", vshift=0.6, reg=dict(method="ROF_TV", regul_param=0.002, iterations=4,
                                                                      time_marching_step=0.002)),
+    # ... together with the Group-Huber ring term (the unfused residual + tomo_sino_add_ring)
+    dict(method="FISTA", nz=12, os=3, fid="LS", vshift=1.2, ring={"lambda": 2e-4, "accelerate": 6},
+         reg=dict(method="PD_TV", regul_param=0.002, iterations=6)),
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['method']}-os{c['os']}-{c['fid']}-{c['reg']['method']}" + ("-vertical-cor" if c.get("vshift") else ""))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['method']}-os{c['os']}-{c['fid']}-{c['reg']['method']}" + ("-vertical-cor" if c.get("vshift") else "") + ("-ring" if c.get("ring") else ""))
 def test_two_rank_reconstruction_matches_whole_volume(case):
     mp.start_processes(_worker, args=(2, _free_port(), case), nprocs=2, join=True, start_method="spawn")
 

@@ -63,7 +63,8 @@ def test_swls_limits(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["gh_ls_os_pdtv", "gh_pwls", "swls_os", "gh_2d"])
+@pytest.mark.parametrize("case", ["gh_ls_os_pdtv", "gh_pwls", "swls_os", "gh_2d", "gh_ls_os_pdtv_vertical", "gh_pwls_vertical",
+                                  "swls_os_vertical"])
 def test_ring_terms_hip_vs_oracle(oracle, case):
     """RecToolsIRCuPy.FISTA with the ring-term keys against the oracle's restatement, bit for bit"""
     import torch
@@ -71,10 +72,14 @@ def test_ring_terms_hip_vs_oracle(oracle, case):
     O = oracle
     angles, clean, striped = _striped_data(O, nz=5, n=72, na=45)
     nz, na, n = striped.shape
+    cor = 0.0
+    if case.endswith("_vertical"):   # a vertical CoR component: the row resampling sits between projector and ring-term residual
+        case = case[:-len("_vertical")]
+        cor = np.stack([np.linspace(-1.0, 1.5, na), 1.3 * np.cos(np.linspace(0.3, 2.9, na))], axis=1)
     if case == "gh_2d":
         striped, nz = striped[2:3], 1
     os_n = {"gh_ls_os_pdtv": 5, "gh_pwls": 1, "swls_os": 3, "gh_2d": 3}[case]
-    P = O.Projector(nz, n, n, angles, 0.0, os_n)
+    P = O.Projector(nz, n, n, angles, cor, os_n)
     L = O.power_method(P, np.random.default_rng(0).standard_normal((nz, n, n)).astype(np.float32))
     data = np.abs(striped) + np.float32(0.05) if case in ("gh_pwls", "swls_os") else striped
     d = {"projection_data": torch.from_numpy(np.ascontiguousarray(data[0] if case == "gh_2d" else data)).cuda(),
@@ -98,7 +103,7 @@ def test_ring_terms_hip_vs_oracle(oracle, case):
         ring = {"lambda": 1e-4, "accelerate": 4}
     from tomobar_amd import ops
     ops.set_variant("pdtv", 22)   # the ring terms are under test: PD_TV with the reference's roundings keeps the comparison bit for bit
-    rt = RecToolsIRCuPy(n, 0, None if case == "gh_2d" else nz, 0.0, angles, n, 0, os_n if os_n > 1 else None)
+    rt = RecToolsIRCuPy(n, 0, None if case == "gh_2d" else nz, cor, angles, n, 0, os_n if os_n > 1 else None)
     got = rt.FISTA(d, alg, reg)
     torch.cuda.synchronize()
     want = O.fista(P, data, 3, L, True, full_reg, fid, ring=ring, beta_swls=beta)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "tomo_swls_apply": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tomo_ring_gh_update": (_i, [_vp, _vp, _vp, _f, _f, _sz, _vp]),
     "tomo_shift_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _vp]),
+    "tomo_sino_add_ring": (_i, [_vp, _vp, _f, _i, _i, _i, _vp]),
     "tomo_sino_residual": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "tomo_bp3d_fista": (_i, [_vp, _i, _vp, _vp, _vp, _f, _i, _vp]),
     "tomo_bp3d_fista_momentum": (_i, [_vp, _i, _vp, _vp, _vp, _f, _f, _i, _vp]),

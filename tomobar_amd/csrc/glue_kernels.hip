@@ -456,6 +456,21 @@ extern "C" int tomo_pwls_max(const float *b, size_t count, float *out_host, void
     return rc;
 }
 
+// res[z, a, u] += scale * ring[z, u]: the Group-Huber offsets added to an already formed LS residual (the vertical-CoR path,
+// where the row resampling sits between the projector and the residual; one rounding for the product, one for the sum, as the
+// fused epilogue of tomo_fp3d_residual_ring)
+__global__ __launch_bounds__(256) void sino_add_ring_kernel(float *__restrict__ res, const float *__restrict__ ring, float scale,
+                                                            int nz, int na_s, int nu)
+{
+    const size_t total = (size_t)nz * na_s * nu;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int u = (int)(i % nu);
+        const int z = (int)(i / ((size_t)nu * na_s));
+        const float t = scale * ring[(size_t)z * nu + u];
+        res[i] = res[i] + t;
+    }
+}
+
 extern "C" int tomo_pwls_weights_scaled(const float *b, float *w, size_t count, float wmax, void *stream)
 {
     return ew_launch<1, 1>(b, nullptr, nullptr, w, nullptr, count, stream, PwlsF{wmax});
@@ -482,6 +497,17 @@ extern "C" int tomo_sino_residual(const float *ax_dev, const float *b_full_dev, 
     if (total == 0) return TOMO_OK;
     sino_residual_kernel<<<(unsigned)std::min<size_t>((total + 255) / 256, 8192), 256, 0, as_stream(stream)>>>(
         ax_dev, b_full_dev, fidelity == TOMO_FID_PWLS ? w_full_dev : nullptr, src_dev, nz, na_s, na_full, nu, fidelity, gathered, res_dev);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
+extern "C" int tomo_sino_add_ring(float *res_dev, const float *ring_dev, float ring_scale, int nz, int na_s, int nu, void *stream)
+{
+    TOMO_REQUIRE(res_dev && ring_dev && nz > 0 && na_s >= 0 && nu > 0, "bad ring-term arguments");
+    const size_t total = (size_t)nz * na_s * nu;
+    if (total == 0) return TOMO_OK;
+    sino_add_ring_kernel<<<(unsigned)std::min<size_t>((total + 255) / 256, 8192), 256, 0, as_stream(stream)>>>(
+        res_dev, ring_dev, ring_scale, nz, na_s, nu);
     TOMO_LAUNCH_CHECK();
     return TOMO_OK;
 }

@@ -311,8 +311,12 @@ class HipTools3D:
 
     def residual_ring(self, vol, b, r_x, accelerate, os_index, out):
         """out = (A_s vol - b_s) + accelerate * r_x[z, u]  (LS residual with the Group-Huber offsets added)."""
-        if self._vshift is not None:
-            raise ValueError("the Group-Huber ring term is not supported together with a vertical CoR component")
+        if self._vshift is not None:   # the row resampling sits between projector and residual: unfused, same roundings
+            self.residual(vol, b, None, "LS", os_index, out)
+            with torch.cuda.device(self._device):
+                self._chk(self._lib.tomo_sino_add_ring(ops.ptr(out), ops.ptr(r_x), float(accelerate), self.nz,
+                                                   self.subset_size(os_index), self.nu, ops.stream_ptr(vol)))
+            return out
         with torch.cuda.device(self._device):
             self._chk(self._lib.tomo_fp3d_residual_ring(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(b), ops.ptr(r_x),
                                                     float(accelerate), ops.ptr(out), ops.stream_ptr(vol)))
