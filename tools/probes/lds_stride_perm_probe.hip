@@ -26,30 +26,45 @@ __global__ __launch_bounds__(1024) void probe(float *out, int iters, float s, in
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int pixel = (m * ((int)threadIdx.x - lane + lane_pixel(lane))) & 1023;
-    float x = x00 + s * (float)pixel;
-    v4f acc = {0, 0, 0, 0};
-    for (int it = 0; it < iters; ++it) {
+    // 8 angles of (nearly) the same slope per thread, as the kernel's angle group: 16 reads in flight per wait
+    float x[8];
+    v4f acc[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float fl = floorf(x);
-            const float w = x - fl;
+    for (int i = 0; i < 8; ++i) { x[i] = x00 + 1.7f * (float)i + s * (float)pixel; acc[i] = v4f{0, 0, 0, 0}; }
+    for (int it = 0; it < iters; ++it) {
+        v4f t0[8], t1[8];
+        float w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float fl = floorf(x[i]);
+            w[i] = x[i] - fl;
             const unsigned addr = ((unsigned)(int)fl & 2047u) * 16u;
-            v4f t0, t1;
-            asm volatile("ds_read_b128 %0, %1" : "=v"(t0) : "v"(addr));
-            asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(t1) : "v"(addr));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            acc += (1.0f - w) * t0 + w * t1;
-            x += slope;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(t0[i]) : "v"(addr));
+            asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(t1[i]) : "v"(addr));
         }
-        x -= 8.0f * slope;   // stay inside the staged window
-        x += 0.37f; if (x > x00 + s * (float)pixel + 16.0f) x -= 16.0f;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[i] += (1.0f - w[i]) * t0[i] + w[i] * t1[i];
+            x[i] += slope;
+        }
+        if ((it & 7) == 7) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] -= 8.0f * slope - 0.37f;   // stay inside the staged window, new fractional phase
+        }
+        if ((it & 255) == 255) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = x00 + 1.7f * (float)i + s * (float)pixel;
+        }
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
+    v4f a4 = acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6] + acc[7];
+    float4 dummy; (void)dummy;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a4.x + a4.y + a4.z + a4.w;
 }
 
 int main()
 {
-    const int blocks = 256, threads = 1024, iters = 4000;
+    const int blocks = 256, threads = 1024, iters = 4096;
     float *out;
     hipMalloc(&out, sizeof(float) * blocks * threads);
     hipEvent_t e0, e1;
@@ -76,7 +91,7 @@ int main()
             hipEventSynchronize(e1);
             float ms;
             hipEventElapsedTime(&ms, e0, e1);
-            const double ns = ms * 1e6 / ((double)(threads / 64) * iters * 8);
+            const double ns = ms * 1e6 / ((double)(threads / 64) * iters * 8);   // 8 read pairs per iteration
             printf(" %5.2f", ns);
             if (j == 0) base = ns;
             if (ns < best) { best = ns; bm = ms_list[j]; }
