@@ -24,6 +24,11 @@ def _copy_halos(states, b):
 @pytest.mark.parametrize("variant", [0, 22, "ranges", pytest.param(2, marks=pytest.mark.dev_variants),
                                      pytest.param(1, marks=pytest.mark.dev_variants)])
 def test_pdtv_slabs_equal_whole_volume(world, half, variant):
+    run_pdtv_slabs(world, half, variant)
+
+
+def run_pdtv_slabs(world, half, variant, shape=(23, 37, 150), iters_list=(7, 4), methodTV=0, nonneg=1, seed=9):
+    """(also driven over random shapes / splits / iteration counts by tools/fuzz_campaign.py --slabs)"""
     ranges = variant == "ranges"  # the overlapped schedule of pd_tv_slab: edge planes first, then the interior
     variant = 0 if ranges else variant
     from tomobar_amd import ops
@@ -31,15 +36,15 @@ def test_pdtv_slabs_equal_whole_volume(world, half, variant):
     from tomobar_amd.slab import PdSlab, _hip_pd_pair, _hip_pd_step, slab_bounds
     ops.set_variant("pdtv", variant)
     try:
-        nz, dy, dx = 23, 37, 150
-        rng = np.random.default_rng(9)
+        nz, dy, dx = shape
+        rng = np.random.default_rng(seed)
         vol = (rng.random((nz, dy, dx)) * 0.3 + (np.indices((nz, dy, dx))[2] > dx // 2) - 0.5).astype(np.float32)
         vd = torch.from_numpy(vol).cuda()
         tau = np.float32(0.04 * 0.1)
         sigma = np.float32(1.0 / (8.0 * tau))
         lt = np.float32(tau / 0.04)
-        for iters in (7, 4):  # pairs + an odd trailing iteration / pairs only
-            want = PD_TV_cupy(vd, 0.04, iters, 0, 1, 8.0, 0, half).cpu().numpy()
+        for iters in iters_list:  # pairs + an odd trailing iteration / pairs only
+            want = PD_TV_cupy(vd, 0.04, iters, methodTV, nonneg, 8.0, 0, half).cpu().numpy()
             states = []
             for r in range(world):
                 z0, z1 = slab_bounds(nz, world, r)
@@ -51,7 +56,7 @@ def test_pdtv_slabs_equal_whole_volume(world, half, variant):
                 for src, dst in zip(hi.initial_send_down(), lo.initial_recv_up()):
                     dst.copy_(src)
             from tomobar_amd.slab import pd_launch_plan
-            args = (sigma, tau, lt, np.float32(1.0), 0, 1)
+            args = (sigma, tau, lt, np.float32(1.0), methodTV, nonneg)
             plan = pd_launch_plan(iters, half)   # the launches tomo_pdtv itself makes: 3 + 3 + ... (2 for binary16 duals)
             for n, k in enumerate(plan):
                 if ranges and k >= 2:
@@ -71,7 +76,7 @@ def test_pdtv_slabs_equal_whole_volume(world, half, variant):
                         s.single(*args)
                 _copy_halos(states, states[0].cur)
             got = torch.cat([s.result() for s in states]).cpu().numpy()
-            assert np.array_equal(got, want), (iters, np.abs(got - want).max())
+            assert np.array_equal(got, want), (shape, world, iters, np.abs(got - want).max())
     finally:
         ops.set_variant("pdtv", 0)
 
@@ -79,13 +84,16 @@ def test_pdtv_slabs_equal_whole_volume(world, half, variant):
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("half", [False, True])
 def test_roftv_slabs_equal_whole_volume(world, half):
+    run_roftv_slabs(world, half)
+
+
+def run_roftv_slabs(world, half, shape=(19, 21, 90), iters=6, seed=10):
     from tomobar_amd.regularisersCuPy import ROF_TV_cupy
     from tomobar_amd.slab import RofSlab, _hip_rof_step, slab_bounds
-    nz, dy, dx = 19, 21, 90
-    rng = np.random.default_rng(10)
+    nz, dy, dx = shape
+    rng = np.random.default_rng(seed)
     vol = (rng.random((nz, dy, dx)) * 0.3 + (np.indices((nz, dy, dx))[2] > dx // 2)).astype(np.float32)
     vd = torch.from_numpy(vol).cuda()
-    iters = 6
     want = ROF_TV_cupy(vd, 0.05, iters, 0.005, 0, half).cpu().numpy()
     states = []
     for r in range(world):
@@ -105,7 +113,7 @@ def test_roftv_slabs_equal_whole_volume(world, half):
             s.step(it, np.float32(0.05), np.float32(0.005))
         _copy_halos(states, (it + 1) & 1)
     got = torch.cat([s.local(s.U[iters & 1]) for s in states]).cpu().numpy()
-    assert np.array_equal(got, want), np.abs(got - want).max()
+    assert np.array_equal(got, want), (shape, world, iters, np.abs(got - want).max())
 
 
 def test_halo_pack_unpack_round_trip():

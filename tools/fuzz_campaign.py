@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--seed0", type=int, default=100)
     ap.add_argument("--only-dense", action="store_true")
     ap.add_argument("--skip-dense", action="store_true")
+    ap.add_argument("--slabs", action="store_true", help="only the z-slab TV drivers: random shapes, splits into 2..5 slabs, "
+                    "iteration counts, schedules (lockstep / boundary-first), float32 and binary16 duals")
     args = ap.parse_args()
     import torch
     import test_gpu_parity as T
@@ -57,8 +59,9 @@ def main():
         try:
             fn(*a)
         except Exception as e:   # noqa: BLE001 -- the campaign records and goes on
-            failures.append((name, a[2:] if len(a) > 2 else a, repr(e)[:300]))
-            print(f"FAIL {name} {a[2:]}: {e!r}"[:600], flush=True)
+            shown = a[2:] if (len(a) > 2 and a[0] is O) else a
+            failures.append((name, shown, repr(e)[:300]))
+            print(f"FAIL {name} {shown}: {e!r}"[:600], flush=True)
             traceback.print_exc(limit=2)
         finally:
             for k in ("bp", "fp", "roftv"):
@@ -70,6 +73,18 @@ def main():
         rng = np.random.default_rng(77000 + seed)
         g = random_geometry(rng)
         g3 = random_geometry(rng, min_os=3)   # the fused tests walk subsets 0..2
+        if args.slabs:
+            import test_gpu_slab as S
+            world = int(rng.integers(2, 6))
+            nz = int(rng.integers(4 * world, 12 * world))
+            shape = (nz, int(rng.integers(9, 80)), int(rng.integers(40, 260)))
+            half = bool(rng.integers(0, 2))
+            variant = [22, "ranges", 0][int(rng.integers(0, 3))]
+            iters = (int(rng.integers(1, 14)),)
+            run("pdtv_slabs", S.run_pdtv_slabs, world, half, variant, shape, iters, int(rng.integers(0, 2)), int(rng.integers(0, 2)), seed)
+            run("roftv_slabs", S.run_roftv_slabs, world, half, shape, int(rng.integers(1, 9)), seed)
+            seed += 1
+            continue
         if args.only_dense:
             from tomobar_amd import _lib
             with _lib.use_flavour("dev"):
