@@ -467,6 +467,67 @@ __global__ __launch_bounds__(256) void momentum_transpose_kernel(const float *__
     }
 }
 
+// The same two kernels on 64 x 64 tiles with 16-byte accesses (round 5): a wave reads four whole 256-byte row segments per
+// instruction instead of two 128-byte ones, and the transposed tile leaves as float4 along y.  Needs n % 4 == 0 and 16-byte
+// aligned arrays (the launchers fall back to the 32 x 32 dword kernels otherwise).  MOMENTUM = false: plain in-plane transpose.
+// LDS tile [64][65]: the transposed read of lane (c, r) touches bank (4c + j + r) mod 64 -- conflict-free for every j.
+// Every stream is touched once per call and is far larger than the L2: non-temporal accesses.  Same-box A/B at 1024^3 (momentum
+// + transposed copy, profiles/r5w_momentum_tile_ab.txt): 32 x 32 dword 3.48 ms, 64 x 64 float4 3.34, + non-temporal 3.25.
+typedef float glue_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_ld4(const float *p)
+{
+    const glue_v4 v = __builtin_nontemporal_load(reinterpret_cast<const glue_v4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_st4(float *p, float4 v)
+{
+    __builtin_nontemporal_store(glue_v4{v.x, v.y, v.z, v.w}, reinterpret_cast<glue_v4 *>(p));
+}
+template <bool MOMENTUM>
+__global__ __launch_bounds__(256) void transpose64_kernel(const float *__restrict__ x, const float *__restrict__ xold,
+                                                          float *__restrict__ xt, float *__restrict__ xt_T, float beta, int n)
+{
+    __shared__ float t[64][65];
+    const size_t zoff = (size_t)blockIdx.z * n * n;
+    const int bx = blockIdx.x * 64, by = blockIdx.y * 64;
+    const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;  // 16 float4 columns x 16 rows per pass
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + 16 * k;
+        const int xx = bx + c4, yy = by + r;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (xx < n && yy < n) {
+            const size_t i = zoff + (size_t)yy * n + xx;
+            const float4 a = nt_ld4(x + i);
+            if (MOMENTUM) {
+                const float4 o = nt_ld4(xold + i);
+                v.x = a.x + beta * (a.x - o.x); v.y = a.y + beta * (a.y - o.y);
+                v.z = a.z + beta * (a.z - o.z); v.w = a.w + beta * (a.w - o.w);
+                nt_st4(xt + i, v);
+            } else {
+                v = a;
+            }
+        }
+        t[r][c4] = v.x; t[r][c4 + 1] = v.y; t[r][c4 + 2] = v.z; t[r][c4 + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + 16 * k;           // column of the tile = row of the transposed copy
+        const int xx = bx + r, yy = by + c4;
+        if (xx < n && yy < n)
+            nt_st4(xt_T + zoff + (size_t)xx * n + yy, make_float4(t[c4][r], t[c4 + 1][r], t[c4 + 2][r], t[c4 + 3][r]));
+    }
+}
+
+static inline bool aligned16(const void *a, const void *b, const void *c, const void *d)
+{
+#ifdef TOMO_GLUE32   // A/B builds only (tools/run_ab.sh): the 32 x 32 dword kernels everywhere
+    return false;
+#endif
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+}
+
 template <bool LERP8, bool RESID>
 __global__ __launch_bounds__(256) void fp_march_kernel(FpArgs a)
 {
@@ -569,8 +630,13 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
         if (rc != TOMO_OK) return rc;
         // tomo_momentum_transposed has just written this volume's transposed copy: use it once, skip the pass
         if (!ready) {
-            dim3 tg(ceil_div(ctx->n, 32), ceil_div(ctx->n, 32), ctx->nz);
-            transpose_inplane_kernel<<<tg, 256, 0, st>>>(vol, (float *)ctx->scratch, ctx->n);
+            if (ctx->n % 4 == 0 && aligned16(vol, ctx->scratch, nullptr, nullptr)) {
+                dim3 tg(ceil_div(ctx->n, 64), ceil_div(ctx->n, 64), ctx->nz);
+                transpose64_kernel<false><<<tg, 256, 0, st>>>(vol, nullptr, nullptr, (float *)ctx->scratch, 0.0f, ctx->n);
+            } else {
+                dim3 tg(ceil_div(ctx->n, 32), ceil_div(ctx->n, 32), ctx->nz);
+                transpose_inplane_kernel<<<tg, 256, 0, st>>>(vol, (float *)ctx->scratch, ctx->n);
+            }
             TOMO_LAUNCH_CHECK();
         }
         a.volT = (const float *)ctx->scratch;
@@ -944,8 +1010,13 @@ extern "C" int tomo_momentum_transposed(tomo_ctx *ctx, const float *x_dev, const
     TOMO_ON_DEVICE(ctx->device);
     int rc = fp_scratch(ctx);
     if (rc != TOMO_OK) return rc;
-    dim3 tg(ceil_div(ctx->n, 32), ceil_div(ctx->n, 32), ctx->nz);
-    momentum_transpose_kernel<<<tg, 256, 0, as_stream(stream)>>>(x_dev, xold_dev, xt_dev, (float *)ctx->scratch, beta, ctx->n);
+    if (ctx->n % 4 == 0 && aligned16(x_dev, xold_dev, xt_dev, ctx->scratch)) {
+        dim3 tg(ceil_div(ctx->n, 64), ceil_div(ctx->n, 64), ctx->nz);
+        transpose64_kernel<true><<<tg, 256, 0, as_stream(stream)>>>(x_dev, xold_dev, xt_dev, (float *)ctx->scratch, beta, ctx->n);
+    } else {
+        dim3 tg(ceil_div(ctx->n, 32), ceil_div(ctx->n, 32), ctx->nz);
+        momentum_transpose_kernel<<<tg, 256, 0, as_stream(stream)>>>(x_dev, xold_dev, xt_dev, (float *)ctx->scratch, beta, ctx->n);
+    }
     TOMO_LAUNCH_CHECK();
     ctx->volT_of = xt_dev;
     ctx->volT_stream = as_stream(stream);
