@@ -307,7 +307,8 @@ def placement_tries() -> int:
 def placement_last():
     """The library's most recent arena placement search: {"bytes", "chosen", "scores_GBps", "fast"} or None if none ran
     yet.  "fast": the kept block beat an earlier candidate by the 8 % that separates the fast class of blocks from the
-    slow one (False: the tries ran out first -- expect the TV launches 4-10 % slower)."""
+    slow one (False: the tries ran out first -- either no candidate was in the fast class: expect the TV launches 4-10 % slower, or
+    all of them were and none stood out: compare the scores, fast blocks of a 34 GB arena score >= 5.23 TB/s)."""
     nbytes, chosen = C.c_size_t(0), C.c_int(-1)
     scores = (C.c_double * 16)()
     n = L.lib().tomo_placement_last(C.byref(nbytes), C.byref(chosen), scores, 16)
