@@ -114,6 +114,10 @@ CASES = [
     dict(method="FISTA", nz=13, os=3, fid="PWLS", vshift=1.7, reg=dict(method="PD_TV", regul_param=0.002, iterations=6)),
     dict(method="ADMM", nz=12, os=1, fid="LS", vshift=0.6, reg=dict(method="ROF_TV", regul_param=0.002, iterations=4,
                                                                      time_marching_step=0.002)),
+    # the Group-Huber ring term in z-slab mode -- what BASELINE configs[4] runs on 8 ranks: the offsets [detY, detX] and their
+    # angle sums are slab-local, the PWLS maximum is all-reduced
+    dict(method="FISTA", nz=14, os=4, fid="PWLS", ring={"lambda": 1e-4, "accelerate": 3},
+         reg=dict(method="PD_TV", regul_param=0.002, iterations=6)),
     # ... together with the Group-Huber ring term (the unfused residual + tomo_sino_add_ring)
     dict(method="FISTA", nz=12, os=3, fid="LS", vshift=1.2, ring={"lambda": 2e-4, "accelerate": 6},
          reg=dict(method="PD_TV", regul_param=0.002, iterations=6)),
