@@ -117,6 +117,38 @@ class OracleTools3D:
             r = bs / np.clip(ax, np.float32(1e-8), None)
         return _put(out, r)
 
+    # -- ring-artefact data terms (Group-Huber offsets / SWLS): the formulas of oracle.fista, one seam call each
+    def residual_ring(self, vol, b, r_x, accelerate, os_index, out):
+        ax = self._fp(np.ascontiguousarray(_np(vol)), self._sub(os_index))
+        res = ax - _np(b)[:, self._idx(os_index), :]
+        return _put(out, res + (np.float32(accelerate) * _np(r_x))[:, None, :])
+
+    def ring_reduce(self, res, w, r_x, l_inv, os_index, r_out):
+        r = _np(res)
+        vec = np.zeros((self.nz, self.nu), np.float32)
+        for a in range(r.shape[1]):
+            vec = vec + r[:, a, :]
+        _put(r_out, _np(r_x) - np.float32(l_inv) * vec)
+        if w is not None:
+            _put(res, r * _np(w)[:, self._idx(os_index), :])
+
+    def swls_apply(self, res, w, beta, os_index):
+        r, ws_ = _np(res), _np(w)[:, self._idx(os_index), :]
+        wr = np.zeros((self.nz, self.nu), np.float32)
+        ws = np.zeros((self.nz, self.nu), np.float32)
+        for a in range(r.shape[1]):
+            wr = wr + ws_[:, a, :] * r[:, a, :]
+            ws = ws + ws_[:, a, :]
+        q = wr / (ws + np.float32(beta))
+        _put(res, ws_ * r - ws_ * q[:, None, :])
+
+    def ring_update(self, r, r_old, r_x, lam, beta):
+        v = _np(r).copy()
+        t = (np.sign(v) * np.maximum(np.abs(v) - np.float32(lam), np.float32(0.0))).astype(np.float32)
+        _put(r_x, t + np.float32(beta) * (t - _np(r_old)))
+        _put(r, t)
+        _put(r_old, t)
+
     def momentum(self, x, x_old, x_t, beta):
         _put(x_t, _np(x) + np.float32(beta) * (_np(x) - _np(x_old)))
 

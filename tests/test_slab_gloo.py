@@ -163,13 +163,18 @@ def _fista_worker(rank, world, port, case):
         np.testing.assert_allclose(L_slab, O.power_method(P, np.concatenate(starts, axis=0)), rtol=1e-4)
         # (with a vertical component the slices are coupled: 15 iterations from ANOTHER start agree to a few per cent only)
         np.testing.assert_allclose(L_slab, L_whole, rtol=5e-2 if case.get("vshift") else 1e-4)
-        reg = dict(case["reg"])
-        full_reg = {"regul_param": 0.001, "iterations": 150, "time_marching_step": 0.005, "PD_LipschitzConstant": 12.0,
-                    "methodTV": 0, **reg}
+        reg = dict(case["reg"]) if case["reg"] else None
+        full_reg = None if reg is None else {"regul_param": 0.001, "iterations": 150, "time_marching_step": 0.005,
+                                             "PD_LipschitzConstant": 12.0, "methodTV": 0, **reg}
         d = {"projection_data": torch.from_numpy(sino[z0:z1].copy()), "data_axes_labels_order": ["detY", "angles", "detX"],
              "data_fidelity": case["fid"]}
+        ring = case.get("ring")
+        if ring:   # Group-Huber offsets [detY, detX] and their angle sums are slab-local; the PWLS maximum is all-reduced
+            d.update(ringGH_lambda=ring["lambda"], ringGH_accelerate=ring["accelerate"])
+        if case["fid"] == "SWLS":
+            d["beta_SWLS"] = 0.3
         if case["method"] == "FISTA":
-            want = O.fista(P, sino, 2, L_whole, True, full_reg, case["fid"])
+            want = O.fista(P, sino, 2, L_whole, True, full_reg, case["fid"], ring=ring, beta_swls=0.3)
             got = rt.FISTA(d, {"iterations": 2, "lipschitz_const": L_whole, "nonnegativity": True,
                                "recon_mask_radius": None}, reg)
         else:
@@ -185,6 +190,10 @@ FISTA_CASES = [
     dict(method="FISTA", nz=8, os=1, fid="LS", reg=dict(method="ROF_TV", regul_param=0.002, iterations=5,
                                                         time_marching_step=0.002)),
     dict(method="ADMM", nz=10, os=3, fid="LS", reg=dict(method="PD_TV", regul_param=0.004, iterations=6)),
+    # ring-artefact data terms in z-slab mode (BASELINE configs[4] runs FISTA-OS + PD_TV + the Group-Huber term on 8 ranks)
+    dict(method="FISTA", nz=10, os=4, fid="PWLS", ring={"lambda": 1e-4, "accelerate": 3},
+         reg=dict(method="PD_TV", regul_param=0.002, iterations=6)),
+    dict(method="FISTA", nz=9, os=3, fid="SWLS", reg=None),
     # vertical CoR component: ghost detector rows travel with every projector call (tomobar_amd.slab.extend_detector_rows)
     dict(method="FISTA", nz=11, os=3, fid="PWLS", vshift=1.7, reg=dict(method="PD_TV", regul_param=0.002, iterations=6)),
     dict(method="ADMM", nz=9, os=1, fid="LS", vshift=0.6, reg=dict(method="ROF_TV", regul_param=0.002, iterations=4,
@@ -192,8 +201,8 @@ FISTA_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", FISTA_CASES, ids=lambda c: f"{c['method']}-os{c['os']}-{c['fid']}-{c['reg']['method']}"
-                         + ("-vertical-cor" if c.get("vshift") else ""))
+@pytest.mark.parametrize("case", FISTA_CASES, ids=lambda c: f"{c['method']}-os{c['os']}-{c['fid']}-{(c['reg'] or {}).get('method')}"
+                         + ("-vertical-cor" if c.get("vshift") else "") + ("-ring" if c.get("ring") else ""))
 def test_slab_reconstruction_drivers_match_whole_volume(case):
     """world-2 gloo run of RecToolsIRCuPy.powermethod / FISTA / ADMM with ``rt.slab`` set: power-method all-reduce, PWLS
     maximum all-reduce and the slab proximal step together; the oracle stands in for the C-ABI library at the projector /
