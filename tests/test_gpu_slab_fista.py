@@ -110,6 +110,8 @@ CASES = [
     dict(method="FISTA", nz=12, os=1, fid="LS", reg=dict(method="ROF_TV", regul_param=0.002, iterations=5,
                                                          time_marching_step=0.002)),
     dict(method="ADMM", nz=16, os=3, fid="LS", reg=dict(method="PD_TV", regul_param=0.004, iterations=6)),
+    # ADMM + ROF_TV without subsets: what BASELINE configs[3] runs on 4 ranks
+    dict(method="ADMM", nz=15, os=1, fid="LS", reg=dict(method="ROF_TV", regul_param=0.003, iterations=5, time_marching_step=0.002)),
     # vertical CoR component in z-slab mode (round 5): ghost detector rows travel with the projector calls
     dict(method="FISTA", nz=13, os=3, fid="PWLS", vshift=1.7, reg=dict(method="PD_TV", regul_param=0.002, iterations=6)),
     dict(method="ADMM", nz=12, os=1, fid="LS", vshift=0.6, reg=dict(method="ROF_TV", regul_param=0.002, iterations=4,

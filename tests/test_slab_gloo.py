@@ -194,6 +194,8 @@ FISTA_CASES = [
     dict(method="FISTA", nz=10, os=4, fid="PWLS", ring={"lambda": 1e-4, "accelerate": 3},
          reg=dict(method="PD_TV", regul_param=0.002, iterations=6)),
     dict(method="FISTA", nz=9, os=3, fid="SWLS", reg=None),
+    # ADMM + ROF_TV without subsets: what BASELINE configs[3] runs on 4 ranks
+    dict(method="ADMM", nz=9, os=1, fid="LS", reg=dict(method="ROF_TV", regul_param=0.003, iterations=5, time_marching_step=0.002)),
     # vertical CoR component: ghost detector rows travel with every projector call (tomobar_amd.slab.extend_detector_rows)
     dict(method="FISTA", nz=11, os=3, fid="PWLS", vshift=1.7, reg=dict(method="PD_TV", regul_param=0.002, iterations=6)),
     dict(method="ADMM", nz=9, os=1, fid="LS", vshift=0.6, reg=dict(method="ROF_TV", regul_param=0.002, iterations=4,
