@@ -126,9 +126,25 @@ CASES = [
 ]
 
 
+def _run_ranks(world, case, backend="gloo", limit_s=600.0):
+    """Spawn the ranks and wait for them with a deadline: a rank stuck in a collective (a transport that never completes)
+    fails the test and is killed instead of stalling the whole suite."""
+    import time
+    ctx = mp.start_processes(_worker, args=(world, _free_port(), case, backend), nprocs=world, join=False, start_method="spawn")
+    deadline = time.time() + limit_s
+    try:
+        while not ctx.join(timeout=5.0):     # raises ProcessRaisedException / ProcessExitedException when a rank fails
+            if time.time() > deadline:
+                raise AssertionError(f"{world} ranks ({backend}) did not finish within {limit_s:.0f} s")
+    finally:
+        for p in ctx.processes:
+            if p.is_alive():
+                p.kill()
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['method']}-os{c['os']}-{c['fid']}-{c['reg']['method']}" + ("-vertical-cor" if c.get("vshift") else "") + ("-ring" if c.get("ring") else ""))
 def test_two_rank_reconstruction_matches_whole_volume(case):
-    mp.start_processes(_worker, args=(2, _free_port(), case), nprocs=2, join=True, start_method="spawn")
+    _run_ranks(2, case)
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -139,4 +155,4 @@ def test_rccl_ranks_one_gpu_each(case, world):
     if torch.cuda.device_count() < world:
         pytest.skip(f"needs {world} GPUs on this node, found {torch.cuda.device_count()}")
     case = dict(case, nz=case["nz"] * 2)
-    mp.start_processes(_worker, args=(world, _free_port(), case, "nccl"), nprocs=world, join=True, start_method="spawn")
+    _run_ranks(world, case, "nccl", limit_s=300.0)
