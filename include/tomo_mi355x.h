@@ -225,7 +225,7 @@ int tomo_pwls_weights(const float *b_dev, float *w_dev, size_t count, void *stre
 int tomo_pwls_max(const float *b_dev, size_t count, float *out_host, void *stream);
 int tomo_pwls_weights_scaled(const float *b_dev, float *w_dev, size_t count, float wmax, void *stream);
 /* diagnostics: nin-read / nout-write streaming kernel (vec = 4: float4 accesses, 1: dword) used to calibrate the
- * achievable HBM rate for a kernel's read/write mix (tools/stream_probe.py) */
+ * achievable HBM rate for a kernel's read/write mix (tools/archive/probes/stream_probe.py) */
 int tomo_diag_stream(const float *const *in_dev, int nin, float *const *out_dev, int nout, size_t count,
                      int vec, int grid, void *stream);
 

@@ -122,7 +122,9 @@ def _z_varying_volume(nz, dy, dx):
 @pytest.mark.parametrize("half", [False, True])
 def test_full_size_pdtv_z_varying_cone(oracle, half, pd_arith):
     from tomobar_amd.regularisersCuPy import PD_TV_cupy
-    nz, dy, dx, iters = 1024, 1024, 1024, 6
+    # 9 iterations = launch plan [3, 3, 3] (round 6): the first launch (zero duals in), the STEADY-STATE launch (reads and writes
+    # the duals: 8 of the 10 launches of the bench's prox) and the last one (no dual stores); 6 iterations never ran the middle one
+    nz, dy, dx, iters = 1024, 1024, 1024, 9
     vol = _z_varying_volume(nz, dy, dx)
     got = PD_TV_cupy(vol, 0.04, iters, 0, 1, 12.0, 0, half)
     for z0, z1, v0, v1 in _cone_cases(nz, iters):
@@ -130,9 +132,11 @@ def test_full_size_pdtv_z_varying_cone(oracle, half, pd_arith):
         w = torch.from_numpy(want[v0 - z0:v1 - z0]).cuda()
         assert v1 - v0 >= 16
         pd_arith.check(got[v0:v1], w, half=half, what=f"1024^3 cone, slab at {z0}")
-        # the cone argument itself: one plane further the slab's artificial boundary has arrived (interior slabs only)
+        # the slab's boundary IS artificial (interior slabs only): next to it the slab result differs from the whole-volume
+        # one.  (The perturbation decays by a factor per plane it crosses; after 8 planes it is below half an ulp, so "one
+        # plane outside the cone differs" -- the round-4 form of this check at 6 iterations -- no longer holds at 9.)
         if z0 > 0:
-            assert not np.array_equal(want[v0 - z0 - 1], got[v0 - 1].cpu().numpy())
+            assert not np.array_equal(want[1], got[z0 + 1].cpu().numpy())
 
 
 def test_full_size_roftv_z_varying_cone(oracle):

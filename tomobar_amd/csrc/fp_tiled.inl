@@ -23,12 +23,14 @@ struct FpTiledArgs {
     const float *ring;       // Group-Huber offsets r_x [nz][nu] added to the residual (null: none)
     float ring_scale;        // ringGH_accelerate
     int fidelity, gathered;
+    int robust;              // TOMO_ROBUST_* re-weighting of the LS / PWLS residual
+    float rdelta;
     int zquad;               // residual epilogue: out is [ceil(nz/4)][na][nu][4] (TOMO_RESIDUAL_ZQUAD, see tomo_mi355x.h)
     int wpitch;              // LDS pitch (float4 units) per staged row, <= 256 * passes <= 1024
     int nut, ngroups, nzb;   // detector tiles, angle groups, slice quads
     int bt;                  // whole-row form: detector pixels per tile = threads launched (a multiple of 64, <= 1024)
 #if TOMO_DEV
-    int probe;               // measurement only (tools/fp_stage_probe.py): 16 = skip the staging (global loads + LDS writes), 32 = the LDS writes only
+    int probe;               // measurement only (tools/archive/probes/fp_stage_probe.py): 16 = skip the staging (global loads + LDS writes), 32 = the LDS writes only
 #else
     static constexpr int probe = 0;  // the shipped flavour carries no measurement switches
 #endif
@@ -242,20 +244,7 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
                 const int z = z0 + zz;
                 if (z < a.nz) {
                     float val = acc[i][zz] * t.scale;
-                    if (RESID) {
-                        const size_t gi = ((size_t)z * a.na + k_a) * a.nu + iu;
-                        const size_t fi = ((size_t)z * a.na_full + t.src) * a.nu + iu;
-                        const float bv = a.b[(a.gathered & TOMO_GATHERED_B) ? gi : fi];
-                        if (a.fidelity == TOMO_FID_KL || a.fidelity == TOMO_FID_RATIO) {
-                            const float ax = val < 1e-8f ? 1e-8f : val;
-                            const float qv = bv / ax;
-                            val = (a.fidelity == TOMO_FID_KL) ? 1.0f - qv : qv;
-                        } else {
-                            val = val - bv;
-                            if (a.ring) val = val + a.ring_scale * a.ring[(size_t)z * a.nu + iu];
-                            if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
-                        }
-                    }
+                    if (RESID) val = fp_residual_value(a, val, z, k_a, t.src, iu);
                     v4[zz] = val;
                     if (!(RESID && a.zquad)) a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
                 }
@@ -405,20 +394,7 @@ __global__ __launch_bounds__(BT) void fp_tiled_sync_kernel(FpTiledArgs a, int kc
             const int z = z0 + zz;
             if (z >= a.nz) break;
             float val = acc[i][zz] * t.scale;
-            if (RESID) {
-                const size_t gi = ((size_t)z * a.na + k_a) * a.nu + iu;
-                const size_t fi = ((size_t)z * a.na_full + t.src) * a.nu + iu;
-                const float bv = a.b[(a.gathered & TOMO_GATHERED_B) ? gi : fi];
-                if (a.fidelity == TOMO_FID_KL || a.fidelity == TOMO_FID_RATIO) {
-                    const float ax = val < 1e-8f ? 1e-8f : val;
-                    const float qv = bv / ax;
-                    val = (a.fidelity == TOMO_FID_KL) ? 1.0f - qv : qv;
-                } else {
-                    val = val - bv;
-                    if (a.ring) val = val + a.ring_scale * a.ring[(size_t)z * a.nu + iu];
-                    if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
-                }
-            }
+            if (RESID) val = fp_residual_value(a, val, z, k_a, t.src, iu);
             v4[zz] = val;
             if (!(RESID && a.zquad)) a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
         }

@@ -442,7 +442,7 @@ static int pd_zmarch_xk_launch(PdArgs a, hipStream_t st, long want_per_simd = 32
     if (blocks > 0x7fffffffL) return tomo_fail(TOMO_E_INVALID, "volume too large for one PD_TV launch");
     size_t dyn = 0;
 #if TOMO_DEV
-    // measurement only (tools/pd_halo_probe.py, bit 8): reserve 72 KiB of dynamic LDS on top of the kernel's own 80 KiB, so
+    // measurement only (tools/archive/probes/pd_halo_probe.py, bit 8): reserve 72 KiB of dynamic LDS on top of the kernel's own 80 KiB, so
     // that ONE workgroup fits a CU (one wave per SIMD instead of two) -- what a tiling that spends the second workgroup's
     // LDS on a prefetch buffer would have to live with
     if (a.probe & 8) {

@@ -37,6 +37,20 @@ __device__ __forceinline__ float lerp_w(float f, float fl)
     return w;
 }
 
+// Robust re-weighting of a data residual (the Huber and Student's-t data terms of the reference's removed RecToolsIR class:
+// _data_["huber_threshold"], _data_["studentst_threshold"], Demos/methods_IR_legacy/DemoFISTA_artifacts2D.py:197,348;
+// formula-level, see include/tomo_mi355x.h): Huber  r <- (delta/|r|) r where |r| > delta;  Student's t  r <- (2/(delta^2 + r^2)) r
+__device__ __forceinline__ float robust_weight(float r, int mode, float delta)
+{
+    if (mode == TOMO_ROBUST_HUBER) {
+        const float ar = fabsf(r);
+        if (ar > delta) r = (delta / ar) * r;
+    } else if (mode == TOMO_ROBUST_STUDENTST) {
+        r = (2.0f / (delta * delta + r * r)) * r;
+    }
+    return r;
+}
+
 enum { EPI_PLAIN = 0, EPI_FISTA = 1, EPI_FISTA_MOM = 2, EPI_ADMM = 3 };
 
 struct BpArgs {
@@ -420,7 +434,28 @@ struct FpArgs {
     int fidelity;
     int gathered;            // bit0: b is the gathered subset, bit1: w is
     int zquad;               // residual epilogue: out is [ceil(nz/4)][na][nu][4] (TOMO_RESIDUAL_ZQUAD)
+    int robust;              // TOMO_ROBUST_*: re-weighting of the LS / PWLS residual (Huber, Student's t)
+    float rdelta;            // its threshold
 };
+
+// The residual epilogue of every forward-projection kernel (data_fidelities.py:28-39 + the ring offsets + the robust
+// re-weightings): `val` = (A_s x)[z, k_a, iu]; Args = FpArgs or FpTiledArgs (same field names).
+template <class Args>
+__device__ __forceinline__ float fp_residual_value(const Args &a, float val, int z, int k_a, int src, int iu)
+{
+    const size_t gi = ((size_t)z * a.na + k_a) * a.nu + iu;          // gathered layout
+    const size_t fi = ((size_t)z * a.na_full + src) * a.nu + iu;     // full-sinogram layout
+    const float bv = a.b[(a.gathered & TOMO_GATHERED_B) ? gi : fi];
+    if (a.fidelity == TOMO_FID_KL || a.fidelity == TOMO_FID_RATIO) {
+        const float ax = val < 1e-8f ? 1e-8f : val;
+        const float q = bv / ax;
+        return (a.fidelity == TOMO_FID_KL) ? 1.0f - q : q;
+    }
+    val = val - bv;
+    if (a.ring) val = val + a.ring_scale * a.ring[(size_t)z * a.nu + iu];
+    if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
+    return robust_weight(val, a.robust, a.rdelta);
+}
 
 __global__ __launch_bounds__(256) void transpose_inplane_kernel(const float *__restrict__ in, float *__restrict__ out, int n)
 {
@@ -571,20 +606,7 @@ __global__ __launch_bounds__(256) void fp_march_kernel(FpArgs a)
         if (!zok[zz]) continue;
         const int z = z0 + zz;
         float val = acc[zz] * t.scale;
-        if (RESID) {
-            const size_t gi = ((size_t)z * a.na + k_a) * a.nu + iu;          // gathered layout
-            const size_t fi = ((size_t)z * a.na_full + t.src) * a.nu + iu;   // full-sinogram layout
-            const float bv = a.b[(a.gathered & TOMO_GATHERED_B) ? gi : fi];
-            if (a.fidelity == TOMO_FID_KL || a.fidelity == TOMO_FID_RATIO) {
-                const float ax = val < 1e-8f ? 1e-8f : val;
-                const float q = bv / ax;
-                val = (a.fidelity == TOMO_FID_KL) ? 1.0f - q : q;
-            } else {
-                val = val - bv;
-                if (a.ring) val = val + a.ring_scale * a.ring[(size_t)z * a.nu + iu];
-                if (a.w) val = val * a.w[(a.gathered & TOMO_GATHERED_W) ? gi : fi];
-            }
-        }
+        if (RESID) val = fp_residual_value(a, val, z, k_a, t.src, iu);
         v4[zz] = val;
         if (!(RESID && a.zquad)) a.out[((size_t)z * a.na + k_a) * a.nu + iu] = val;
     }
@@ -608,7 +630,8 @@ int fp_scratch(tomo_ctx *ctx)
 }
 
 int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const float *w, int gathered, int fidelity,
-           float *out, void *stream, const float *ring = nullptr, float ring_scale = 0.0f, int zquad = 0)
+           float *out, void *stream, const float *ring = nullptr, float ring_scale = 0.0f, int zquad = 0,
+           int robust = TOMO_ROBUST_NONE, float rdelta = 0.0f)
 {
     TOMO_REQUIRE(ctx != nullptr, "ctx is NULL");
     TOMO_REQUIRE(vol != nullptr && out != nullptr, "NULL data pointer");
@@ -645,6 +668,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
     a.nz = ctx->nz; a.n = ctx->n; a.nu = ctx->nu; a.na = s.size; a.na_full = ctx->na;
     a.out = out; a.b = b; a.w = w; a.fidelity = fidelity; a.gathered = gathered;
     a.ring = ring; a.ring_scale = ring_scale;
+    a.robust = (b != nullptr) ? robust : TOMO_ROBUST_NONE; a.rdelta = rdelta;
     a.zquad = (b != nullptr) ? zquad : 0;
     if (a.zquad && (((uintptr_t)out) & 15) != 0)
         return tomo_fail(TOMO_E_INVALID, "the quad-interleaved residual must be 16-byte aligned");
@@ -711,7 +735,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
             t.n_class = nc;
             t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
             t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
-            t.ring = ring; t.ring_scale = ring_scale; t.zquad = a.zquad;
+            t.ring = ring; t.ring_scale = ring_scale; t.zquad = a.zquad; t.robust = a.robust; t.rdelta = a.rdelta;
             t.wpitch = wp;
 #if TOMO_DEV
             t.probe = g_probe;
@@ -774,7 +798,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
             t.n_class = nc;
             t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
             t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
-            t.ring = ring; t.ring_scale = ring_scale; t.zquad = a.zquad;
+            t.ring = ring; t.ring_scale = ring_scale; t.zquad = a.zquad; t.robust = a.robust; t.rdelta = a.rdelta;
             t.wpitch = s.wbound16[c];
 #if TOMO_DEV
             t.probe = g_probe;
@@ -883,7 +907,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 t.n_class = nc;
                 t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
                 t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
-                t.ring = ring; t.ring_scale = ring_scale; t.zquad = a.zquad;
+                t.ring = ring; t.ring_scale = ring_scale; t.zquad = a.zquad; t.robust = a.robust; t.rdelta = a.rdelta;
                 t.wpitch = s.wbound[c];
     #if TOMO_DEV
             t.probe = g_probe;
@@ -983,6 +1007,19 @@ extern "C" int tomo_fp3d_residual(tomo_ctx *ctx, int subset, const float *vol_de
     TOMO_REQUIRE(fidelity != TOMO_FID_PWLS || w_full_dev != nullptr, "PWLS needs the weights");
     return fp_run(ctx, subset, vol_dev, b_full_dev, fidelity == TOMO_FID_PWLS ? w_full_dev : nullptr, gathered,
                   fidelity, res_dev, stream, nullptr, 0.0f, ctx ? ctx->res_layout : 0);
+}
+
+extern "C" int tomo_fp3d_residual_robust(tomo_ctx *ctx, int subset, const float *vol_dev, const float *b_full_dev,
+                                         const float *w_full_dev, int gathered, int fidelity, int robust, float delta,
+                                         float *res_dev, void *stream)
+{
+    TOMO_REQUIRE(b_full_dev != nullptr, "projection data pointer is NULL");
+    TOMO_REQUIRE(fidelity == TOMO_FID_LS || fidelity == TOMO_FID_PWLS, "the Huber / Student's-t re-weighting applies to the LS and PWLS residuals");
+    TOMO_REQUIRE(fidelity != TOMO_FID_PWLS || w_full_dev != nullptr, "PWLS needs the weights");
+    TOMO_REQUIRE(robust == TOMO_ROBUST_NONE || robust == TOMO_ROBUST_HUBER || robust == TOMO_ROBUST_STUDENTST, "unknown robust mode %d", robust);
+    TOMO_REQUIRE(robust == TOMO_ROBUST_NONE || delta > 0.0f, "the Huber / Student's-t threshold must be positive");
+    return fp_run(ctx, subset, vol_dev, b_full_dev, fidelity == TOMO_FID_PWLS ? w_full_dev : nullptr, gathered,
+                  fidelity, res_dev, stream, nullptr, 0.0f, ctx ? ctx->res_layout : 0, robust, delta);
 }
 
 extern "C" int tomo_ctx_set_residual_layout(tomo_ctx *ctx, int layout)

@@ -208,7 +208,7 @@ struct PdArgs {
     int p_out_skip = 0;  // pd_zmarch_xk: do not store the output duals (last launch of a prox)
     float nn_thr = 0.0f; // pd_zmarch_xk, relaxed float32 build: iterates below this are clipped to 0 (0 = nonnegativity, -inf = none)
 #if TOMO_DEV
-    int probe = 0;       // measurement only (tools/pd_halo_probe.py): 1 = alias the y halo rows, 2 = the x halo lanes onto the workgroup's own tile, 4 = every plane access goes to plane 0 (cache-resident: what the kernel costs without HBM)
+    int probe = 0;       // measurement only (tools/archive/probes/pd_halo_probe.py): 1 = alias the y halo rows, 2 = the x halo lanes onto the workgroup's own tile, 4 = every plane access goes to plane 0 (cache-resident: what the kernel costs without HBM)
 #else
     static constexpr int probe = 0;  // the shipped flavour carries no measurement switches
 #endif
@@ -458,7 +458,7 @@ int pd_xk3_launch(const PdArgs &a, int variant, hipStream_t st)
 {
 #if TOMO_DEV
     if (variant == 3) return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 2, 2, true, 10>(a, st);
-    if constexpr (sizeof(T) == 4) {  // workgroup shapes of the shipped relaxed kernel, measurement only (tools/pd_time.py)
+    if constexpr (sizeof(T) == 4) {  // workgroup shapes of the shipped relaxed kernel, measurement only (tools/archive/probes/pd_time.py)
         if (variant == 31) return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 1, 4, true, 10>(a, st);
         if (variant == 32) return pd_zmarch_xk_launch<T, NN, AN, 1, 3, 8, 4, 1, true, 10>(a, st);
     }

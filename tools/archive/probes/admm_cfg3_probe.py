@@ -1,9 +1,9 @@
 """BASELINE configs[3] per-GPU share: ADMM + ROF_TV on a 256-slice slab of 2048^2, 1500 angles (one of 4 GPUs).
-Reports seconds per outer iteration and checks the result is finite.  usage: python tools/admm_cfg3_probe.py [nz] [iters]"""
+Reports seconds per outer iteration and checks the result is finite.  usage: python tools/archive/probes/admm_cfg3_probe.py [nz] [iters]"""
 import os
 import sys
 import time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 import torch
 from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy

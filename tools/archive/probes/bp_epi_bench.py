@@ -1,6 +1,6 @@
-"""BP with its fused epilogues at the bench shape: ms per call.  usage: python tools/bp_epi_bench.py [N] [NZ] [NA]"""
+"""BP with its fused epilogues at the bench shape: ms per call.  usage: python tools/archive/probes/bp_epi_bench.py [N] [NZ] [NA]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import statistics
 import numpy as np
 import torch

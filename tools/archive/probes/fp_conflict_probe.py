@@ -1,8 +1,8 @@
 """FP timing for angle sets with different detector-axis strides (LDS bank-conflict exposure of the tap reads).
-usage: python tools/fp_conflict_probe.py [N] [NZ]"""
+usage: python tools/archive/probes/fp_conflict_probe.py [N] [NZ]"""
 import os
 import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 import torch
 from tomobar_amd.projector import HipTools3D

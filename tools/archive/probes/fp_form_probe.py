@@ -1,7 +1,7 @@
 """Which FP form runs for a shape, and what it costs (dev flavour: variant 3 lifts the workgroup-count condition of the dense-angle
-form).  usage: TOMO_MI355X_FLAVOUR=dev python tools/fp_form_probe.py N NZ NA"""
+form).  usage: TOMO_MI355X_FLAVOUR=dev python tools/archive/probes/fp_form_probe.py N NZ NA"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np, torch
 from tomobar_amd import _lib, ops
 from tomobar_amd.projector import HipTools3D

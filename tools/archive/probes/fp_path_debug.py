@@ -1,5 +1,5 @@
-import sys, numpy as np, torch
-sys.path.insert(0, ".")
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 from tomobar_amd.projector import HipTools3D
 n, nz, na = 2560, 4, 1800
 H = HipTools3D(n, 0, nz, np.linspace(0, np.pi, na, endpoint=False), 0.0, n, "gpu", 0, 12)

@@ -1,8 +1,8 @@
 """EXPERIMENT (round 5): forward projector staged by LDS-DMA from quad-interleaved volume copies (fp variants 4 = 8 angles, 5 = 16 angles
 per 1024-thread workgroup; dev flavour) against the shipped forms.  The copies are made once per volume pointer (warm-up call), so the
-timings are the projection kernels alone.  usage: python tools/fp_qv_probe.py N NZ NA OS"""
+timings are the projection kernels alone.  usage: python tools/archive/probes/fp_qv_probe.py N NZ NA OS"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 os.environ["TOMO_MI355X_FLAVOUR"] = "dev"
 import statistics
 import numpy as np, torch

@@ -1,7 +1,7 @@
 """What the staging (global loads + LDS writes of the volume rows) costs the forward projector: the probe switch skips it
-(the sampling loop, barriers and epilogue are unchanged; results are garbage); 32 skips only the LDS writes.  usage: python tools/fp_stage_probe.py [N] [NZ] [NA]"""
+(the sampling loop, barriers and epilogue are unchanged; results are garbage); 32 skips only the LDS writes.  usage: python tools/archive/probes/fp_stage_probe.py [N] [NZ] [NA]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import statistics
 import numpy as np
 import torch

@@ -1,9 +1,9 @@
 """Per-iteration time of every iterative driver on one geometry (sanity: no hidden host round trips).
-usage: python tools/ir_methods_probe.py [n] [nz] [angles]"""
+usage: python tools/archive/probes/ir_methods_probe.py [n] [nz] [angles]"""
 import os
 import sys
 import time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 import torch
 from tomobar_amd.methodsIR_CuPy import RecToolsIRCuPy

@@ -1,9 +1,10 @@
 """Time of tomo_momentum_transposed (FISTA momentum + in-plane transposed copy) and of the forward projector's own transpose
-pass at n^2 x nz, HIP events.  usage: python tools/momentum_bench.py [n nz]"""
+pass at n^2 x nz, HIP events.  usage: python tools/archive/probes/momentum_bench.py [n nz]"""
+import os
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 from tomobar_amd.projector import HipTools3D
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024

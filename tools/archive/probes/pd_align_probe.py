@@ -1,7 +1,7 @@
 """Does the PD_TV time depend on where the caller's Input / output arrays sit relative to the library's arena?
-The volume is a view at different byte offsets into one larger allocation.  usage: python tools/pd_align_probe.py [N]"""
+The volume is a view at different byte offsets into one larger allocation.  usage: python tools/archive/probes/pd_align_probe.py [N]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import statistics
 import torch
 from tomobar_amd.regularisersCuPy import PD_TV_cupy

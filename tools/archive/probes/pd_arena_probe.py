@@ -1,8 +1,8 @@
 """Does the PD_TV launch time depend on WHERE the library's scratch arena was allocated?  The arena is per (device, stream):
 the same prox on the same volume is run on several torch streams, each of which makes the library allocate its own 34 GB
-arena, in order.  usage: python tools/pd_arena_probe.py [N] [streams]"""
+arena, in order.  usage: python tools/archive/probes/pd_arena_probe.py [N] [streams]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 from tomobar_amd.regularisersCuPy import PD_TV_cupy
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024

@@ -3,9 +3,9 @@
 is unchanged (results are garbage); bit 4: every plane access goes to plane 0 (cache-resident: the kernel without HBM);
 bit 8 (round 4): ONE workgroup per CU (72 KiB of dynamic LDS reserved on top of the kernel's 80 KiB), i.e. one wave per
 SIMD instead of two -- alone, and with bit 4 (12) = the instruction-issue floor of a single wave per SIMD.
-usage: python tools/pd_halo_probe.py [N] [iters] [variant]"""
+usage: python tools/archive/probes/pd_halo_probe.py [N] [iters] [variant]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import statistics
 import torch
 os.environ.setdefault("TOMO_MI355X_FLAVOUR", "dev")  # A/B variants and measurement switches live in libtomo_mi355x_dev.so

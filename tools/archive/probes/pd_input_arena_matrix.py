@@ -1,8 +1,8 @@
 """Which placement matters to a PD_TV launch: the scratch arena's or the Input / output arrays'?  S arenas (one per torch
 stream, plain hipMalloc: TOMO_MI355X_PLACE_TRIES=1) x S (Input, output) pairs allocated in between; the 30-iteration prox is
-timed for every combination.  usage: TOMO_MI355X_PLACE_TRIES=1 python tools/pd_input_arena_matrix.py [N] [S]"""
+timed for every combination.  usage: TOMO_MI355X_PLACE_TRIES=1 python tools/archive/probes/pd_input_arena_matrix.py [N] [S]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 from tomobar_amd.regularisersCuPy import PD_TV_cupy
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024

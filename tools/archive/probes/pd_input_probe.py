@@ -1,8 +1,8 @@
 """With the library's scratch arena fixed (placed once), does the PD_TV prox time depend on where the CALLER's input / output
 volumes lie?  Twelve candidate input volumes (torch allocations of 4.3 GB, held at once), the same prox on each; then the
-same for the output.  usage: python tools/pd_input_probe.py [N] [count]"""
+same for the output.  usage: python tools/archive/probes/pd_input_probe.py [N] [count]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 from tomobar_amd import ops
 from tomobar_amd.regularisersCuPy import PD_TV_cupy

@@ -1,6 +1,6 @@
-"""Interleaved A/B of PD_TV kernel variants (median and min over rounds): python tools/pd_sweep.py [N] [variants...]"""
+"""Interleaved A/B of PD_TV kernel variants (median and min over rounds): python tools/archive/probes/pd_sweep.py [N] [variants...]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import statistics
 import torch
 os.environ.setdefault("TOMO_MI355X_FLAVOUR", "dev")  # A/B variants and measurement switches live in libtomo_mi355x_dev.so

@@ -1,7 +1,7 @@
 """PD_TV launch time at 1024^3 for a 30-iteration prox (ten three-iteration launches), shipped library: default / exact / binary16.
-usage: python tools/pd_time.py [N] [reps] [NZ]"""
+usage: python tools/archive/probes/pd_time.py [N] [reps] [NZ]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 from tomobar_amd import ops
 from tomobar_amd.regularisersCuPy import PD_TV_cupy

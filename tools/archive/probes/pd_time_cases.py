@@ -1,7 +1,7 @@
 """PD_TV prox time (30 iterations, 1024^3) over the argument combinations that select different kernel instantiations:
-nonneg x methodTV x {float32, binary16 duals} x {default, exact}.  usage: python tools/pd_time_cases.py [N] [reps]"""
+nonneg x methodTV x {float32, binary16 duals} x {default, exact}.  usage: python tools/archive/probes/pd_time_cases.py [N] [reps]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 from tomobar_amd import ops
 from tomobar_amd.regularisersCuPy import PD_TV_cupy

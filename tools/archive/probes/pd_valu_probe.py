@@ -2,7 +2,7 @@
 projection branch), (b) zeros (no wave takes it: ~45 % fewer VALU instructions, identical HBM traffic)."""
 import os
 import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 os.environ.setdefault("TOMO_MI355X_FLAVOUR", "dev")  # A/B variants and measurement switches live in libtomo_mi355x_dev.so
 from tomobar_amd.regularisersCuPy import PD_TV_cupy

@@ -1,6 +1,6 @@
-"""Bit-equality of PD_TV kernel variants that must compute the same roundings: python tools/pd_variant_equal.py A B [A B ...]"""
+"""Bit-equality of PD_TV kernel variants that must compute the same roundings: python tools/archive/probes/pd_variant_equal.py A B [A B ...]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 os.environ.setdefault("TOMO_MI355X_FLAVOUR", "dev")  # A/B variants and measurement switches live in libtomo_mi355x_dev.so
 from tomobar_amd import ops

@@ -1,7 +1,7 @@
 """ROF_TV normalisation arithmetic: error vs the oracle on the noise inputs of tests/test_gpu_ref_tv.py and time per iteration at
 1024^3 for variant 0 (relaxed), 4 (refined rsq/rcp), 5 (Markstein-corrected = the reference's roundings), 2 (compiler IEEE)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np, torch
 from oracle import tomo_oracle as O
 os.environ.setdefault("TOMO_MI355X_FLAVOUR", "dev")  # A/B variants and measurement switches live in libtomo_mi355x_dev.so

@@ -2,7 +2,7 @@
 communicator that has no neighbours (so: the Python-level pair loop, the ghost-less PdSlab buffers, the final copy)."""
 import os
 import sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 from tomobar_amd.regularisersCuPy import PD_TV_cupy
 from tomobar_amd.slab import pd_tv_slab

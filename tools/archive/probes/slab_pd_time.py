@@ -1,7 +1,7 @@
 """PD_TV through the slab driver on one GPU (world 1: no ghosts, no exchange), work arrays placed by the library or
-allocated by torch.  usage: python tools/slab_pd_time.py [N]"""
+allocated by torch.  usage: python tools/archive/probes/slab_pd_time.py [N]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 from tomobar_amd import ops, slab
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024

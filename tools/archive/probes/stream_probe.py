@@ -1,6 +1,6 @@
 """Achievable HBM rate for an (nin reads, nout writes) streaming mix: calibrates roofline expectations."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 from tomobar_amd import _lib
 lib = _lib.lib()

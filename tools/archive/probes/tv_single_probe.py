@@ -1,7 +1,7 @@
 """Times the single-iteration PD_TV kernel (one iteration per call), the two-iteration kernel and ROF_TV at N^3.
-usage: python tools/tv_single_probe.py [N]"""
+usage: python tools/archive/probes/tv_single_probe.py [N]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch
 os.environ.setdefault("TOMO_MI355X_FLAVOUR", "dev")  # A/B variants and measurement switches live in libtomo_mi355x_dev.so
 from tomobar_amd import ops

@@ -10,5 +10,5 @@ timeout 600 python bench.py --steps 2 --warmup 1 --half --no-cpu > gpurun_out/r2
 timeout 600 python bench.py --gpus 2 --steps 1 --warmup 1 --nz 128 --no-cpu > gpurun_out/r2i/bench_n2_dry.json 2> gpurun_out/r2i/bench_n2_dry.err
 timeout 600 python bench.py --gpus 2 --strong --steps 1 --warmup 1 --nz 256 --no-cpu > gpurun_out/r2i/bench_n2_strong_dry.json 2>/dev/null
 timeout 600 python bench.py --steps 2 --warmup 1 --ring 1e-4 --no-cpu > gpurun_out/r2i/bench_ring.json 2>/dev/null
-timeout 600 python tools/admm_cfg3_probe.py > gpurun_out/r2i/admm_cfg3.txt 2>&1
+timeout 600 python tools/archive/probes/admm_cfg3_probe.py > gpurun_out/r2i/admm_cfg3.txt 2>&1
 for f in bench_n1 bench_half bench_n2_dry bench_n2_strong_dry bench_ring; do cut -c1-170 gpurun_out/r2i/$f.json; done; tail -3 gpurun_out/r2i/admm_cfg3.txt

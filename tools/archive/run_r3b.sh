@@ -1,8 +1,8 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r3b; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/pytest.log
-timeout 300 python tools/fp_stage_probe.py 1024 1024 900 12 > $O/fp_stage_probe.txt 2>&1
-timeout 300 python tools/fp_stage_probe.py 2048 256 1500 1 >> $O/fp_stage_probe.txt 2>&1
+timeout 300 python tools/archive/probes/fp_stage_probe.py 1024 1024 900 12 > $O/fp_stage_probe.txt 2>&1
+timeout 300 python tools/archive/probes/fp_stage_probe.py 2048 256 1500 1 >> $O/fp_stage_probe.txt 2>&1
 timeout 600 python bench.py --steps 3 --warmup 1 > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 timeout 600 python bench.py --config cfg1 --steps 50 --warmup 5 > $O/bench_cfg1.json 2> $O/bench_cfg1.err
 timeout 600 python bench.py --gpus 2 --strong --n 256 --nz 64 --angles 180 --os 6 --inner 9 --steps 2 --warmup 1 > $O/bench_2ranks_dryrun.json 2> $O/bench_2ranks_dryrun.err

@@ -19,6 +19,6 @@ timeout 900 python bench.py --config cfg5-share --steps 2 --warmup 1 > $O/bench_
 timeout 600 python bench.py --half --steps 2 --warmup 1 --no-cpu > $O/bench_half.json 2> $O/bench_half.err
 timeout 600 python bench.py --gpus 2 --strong --n 512 --nz 128 --angles 360 --steps 2 --warmup 1 > $O/bench_2ranks_strong_dryrun.json 2> $O/bench_2ranks_strong_dryrun.err
 timeout 300 python tools/kernel_bench.py 1024 1024 75 3 > $O/kernel_bench_1024.txt 2>&1
-timeout 300 python tools/bp_epi_bench.py > $O/bp_epilogues.txt 2>&1
-timeout 300 python tools/pd_halo_probe.py 1024 30 > $O/pd_probes.txt 2>&1
+timeout 300 python tools/archive/probes/bp_epi_bench.py > $O/bp_epilogues.txt 2>&1
+timeout 300 python tools/archive/probes/pd_halo_probe.py 1024 30 > $O/pd_probes.txt 2>&1
 tail -3 $O/pytest.log; tail -1 $O/smoke.log; cat $O/pmc_update.log; for f in bench_n1 bench_default bench_cfg1 bench_cfg3_share bench_cfg5_share bench_half bench_2ranks_strong_dryrun; do cut -c1-160 $O/$f.json; done

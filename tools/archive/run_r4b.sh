@@ -5,7 +5,7 @@ T=${1:-r4b}; O=gpurun_out/$T; mkdir -p $O
 timeout 300 tools/probes/_build/recip_allones_probe > $O/recip_allones_probe.txt 2>&1
 timeout 900 tools/probes/_build/hbm_copy_probe > $O/hbm_copy_probe.txt 2>&1
 cat > /tmp/fpab.sh <<'EOS'
-python tools/fp_conflict_probe.py 1024 1024
+python tools/archive/probes/fp_conflict_probe.py 1024 1024
 python tools/kernel_bench.py 1024 1024 75 3 | grep -E "^(BP|FP)  variant 0"
 python tools/kernel_bench.py 2048 128 750 2 | grep -E "^(BP|FP)  variant 0"
 python tools/kernel_bench.py 2560 128 150 2 | grep -E "^(BP|FP)  variant 0"

@@ -7,8 +7,8 @@ for rep in 1 2; do
   timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu > $O/bench_exact_$rep.json 2> $O/bench_exact_$rep.err
   timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu --relaxed-tv > $O/bench_relaxed_$rep.json 2> $O/bench_relaxed_$rep.err
 done
-timeout 600 python tools/pd_halo_probe.py 1024 30 0 > $O/pd_probes_exact.txt 2>&1
-timeout 600 python tools/pd_halo_probe.py 1024 30 3 > $O/pd_probes_relaxed.txt 2>&1
+timeout 600 python tools/archive/probes/pd_halo_probe.py 1024 30 0 > $O/pd_probes_exact.txt 2>&1
+timeout 600 python tools/archive/probes/pd_halo_probe.py 1024 30 3 > $O/pd_probes_relaxed.txt 2>&1
 timeout 300 tools/probes/_build/lds_rate_probe > $O/lds_rate_probe.txt 2>&1
 timeout 300 tools/probes/_build/recip_allones_probe > $O/recip_allones_probe.txt 2>&1
 timeout 300 python tools/tv2d_bench.py > $O/tv2d_bench.txt 2>&1

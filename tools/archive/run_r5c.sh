@@ -5,7 +5,7 @@ O=gpurun_out/r5c; mkdir -p $O
 timeout 600 python -m pytest tests/test_cupy_surface.py tests/test_gpu_slab.py tests/test_gpu_slab_fista.py tests/test_host_logic.py -x -q > $O/pytest_subset.log 2>&1; echo "pytest rc $?" >> $O/pytest_subset.log
 tail -5 $O/pytest_subset.log
 # ---- FP on the configs[3] share: staging / LDS writes / sampling split, then counters of the same call
-timeout 600 python tools/fp_stage_probe.py 2048 256 1500 1 2>/dev/null | grep -v amdgpu > $O/fp_stage_probe_cfg3_share.txt
+timeout 600 python tools/archive/probes/fp_stage_probe.py 2048 256 1500 1 2>/dev/null | grep -v amdgpu > $O/fp_stage_probe_cfg3_share.txt
 cat $O/fp_stage_probe_cfg3_share.txt
 PMC_N=2048 PMC_NZ=256 PMC_NA=1500 PMC_TIMEOUT=240 PMC_GROUPS="SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES;GRBM_GUI_ACTIVE;FETCH_SIZE;WRITE_SIZE;SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES;TCC_HIT_sum TCC_MISS_sum" bash tools/pmc_run.sh r5c_fp fp > $O/pmc_fp_cfg3_share.txt 2>&1
 grep -v native $O/pmc_fp_cfg3_share.txt | tail -8

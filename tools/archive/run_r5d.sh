@@ -5,7 +5,7 @@ timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_recon.py te
 tail -6 $O/pytest_gpu.log
 for shape in "1024 1024 75" "2560 270 150" "2048 256 1500"; do
   echo "== BP epilogues, N NZ NA = $shape" >> $O/bp_epi.txt
-  timeout 300 python tools/bp_epi_bench.py $shape 2>/dev/null | grep -v amdgpu >> $O/bp_epi.txt
+  timeout 300 python tools/archive/probes/bp_epi_bench.py $shape 2>/dev/null | grep -v amdgpu >> $O/bp_epi.txt
 done
 cat $O/bp_epi.txt
 timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu --no-pmc > $O/bench_line.json 2> $O/bench.err

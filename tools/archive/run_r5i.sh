@@ -6,7 +6,7 @@ for rep in 1 2; do
   for L in ab/lib_*.so; do
     n=$(basename $L .so); cp $L tomobar_amd/libtomo_mi355x.so
     echo "== $n (pass $rep)" >> $O/bp_epi.txt
-    TOMO_MI355X_FLAVOUR=shipped timeout 200 python tools/bp_epi_bench.py 1024 1024 75 2>/dev/null | grep "quad\|plain" >> $O/bp_epi.txt
+    TOMO_MI355X_FLAVOUR=shipped timeout 200 python tools/archive/probes/bp_epi_bench.py 1024 1024 75 2>/dev/null | grep "quad\|plain" >> $O/bp_epi.txt
   done
 done
 for L in ab/lib_*.so; do

@@ -13,7 +13,7 @@ d = json.load(open("gpurun_out/r5p/b.json"))
 print(f"{sys.argv[1]:16s} {sys.argv[2] or 'default (relaxed)':18s}: {d['value']:.4f} it/s  PD_TV {d['kernels']['pdtv']['avg_ms']:.3f} ms  fast block {d['placement']['fast']}")
 PY
     done
-    TOMO_MI355X_FLAVOUR=shipped timeout 200 python tools/pd_time.py 1024 3 2>/dev/null | grep "exact\|default" | sed "s/^/$n  uniform-random volume: /" >> $O/summary.txt
+    TOMO_MI355X_FLAVOUR=shipped timeout 200 python tools/archive/probes/pd_time.py 1024 3 2>/dev/null | grep "exact\|default" | sed "s/^/$n  uniform-random volume: /" >> $O/summary.txt
   done
 done
 cp ab/lib_exact_skip.so tomobar_amd/libtomo_mi355x.so

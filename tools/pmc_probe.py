@@ -18,7 +18,7 @@ NA = int(sys.argv[4]) if len(sys.argv) > 4 else 75
 vol = torch.rand((NZ, N, N), device="cuda")
 out = torch.empty_like(vol)
 if os.environ.get("PMC_PROBE", "0") != "0":
-    ops.set_variant("probe", int(os.environ["PMC_PROBE"]))   # measurement switches (tools/pd_halo_probe.py)
+    ops.set_variant("probe", int(os.environ["PMC_PROBE"]))   # measurement switches (tools/archive/probes/pd_halo_probe.py)
 if what.startswith("pdtv"):
     ops.set_variant("pdtv", int(what[4:].rstrip("h")))
     PD_TV_cupy(vol, 0.01, int(os.environ.get("PMC_PD_ITERS", "6")), 0, 1, 12.0, 0, what.endswith("h"), out=out)  # 3 + 3 (shipped f32) or 2 + 2 + 2; 9 = first (zero duals) + middle + last (no dual stores) launch

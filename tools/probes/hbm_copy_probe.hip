@@ -1,5 +1,5 @@
 // Ceiling probe (round 4): what does a plain streaming copy reach on THIS box?  The MI355X guide quotes 6.29 TB/s for a
-// float4 copy (MI355X_MICROARCH.md:35,293); tools/stream_probe.py measured 5.1-5.3 TB/s with the library's diag kernel.
+// float4 copy (MI355X_MICROARCH.md:35,293); tools/archive/probes/stream_probe.py measured 5.1-5.3 TB/s with the library's diag kernel.
 // This probe sweeps everything a copy kernel can choose: 16 B per lane, one element per thread or grid-stride with 1/2/4/8
 // independent loads in flight, 256..1024 threads, grid sizes, non-temporal loads / stores, array sizes, plus read-only
 // and write-only streams and the runtime's own hipMemcpyAsync / hipMemsetAsync.
