@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* raised whenever an entry point is added or a signature changes (tomobar_amd/_lib.py checks it at load) */
-#define TOMO_ABI_VERSION 5
+#define TOMO_ABI_VERSION 6
 
 enum {
     TOMO_OK = 0,
@@ -115,6 +115,20 @@ int tomo_bp3d(tomo_ctx *ctx, int subset, const float *sino_dev, float *vol_dev, 
 #define TOMO_GATHERED_W 2
 int tomo_fp3d_residual(tomo_ctx *ctx, int subset, const float *vol_dev, const float *b_dev,
                        const float *w_dev, int gathered, int fidelity, float *res_dev, void *stream);
+
+/* ---------------------------------------------------------------- robust data terms: Huber and Student's t
+ * Listed as supported data fidelities in docs/source/introduction/about.rst:38 and driven by _data_["huber_threshold"] /
+ * _data_["studentst_threshold"] in Demos/methods_IR_legacy/DemoFISTA_artifacts2D.py:197,263,307,348 -- keys of the reference's
+ * removed RecToolsIR class; this reference version has no implementation (supp/dicts.py:85-88), so parity is formula-level
+ * (oracle/tomo_oracle.py fista(..., huber=, studentst=)), UNPINNED.  Both re-weight the (weighted) residual r before A^T:
+ *   TOMO_ROBUST_HUBER     : r <- (delta / |r|) r  where |r| > delta   (gradient of the Huber function of threshold delta)
+ *   TOMO_ROBUST_STUDENTST : r <- (2 / (delta^2 + r^2)) r              (gradient of log(delta^2 + r^2), [KAZ1_2017])
+ * tomo_fp3d_residual_robust = tomo_fp3d_residual (LS / PWLS) with the re-weighting in the same epilogue (either residual
+ * layout); tomo_sino_robust re-weights an existing residual of `count` floats in place (ring-term / vertical-CoR paths). */
+enum { TOMO_ROBUST_NONE = 0, TOMO_ROBUST_HUBER = 1, TOMO_ROBUST_STUDENTST = 2 };
+int tomo_fp3d_residual_robust(tomo_ctx *ctx, int subset, const float *vol_dev, const float *b_dev, const float *w_dev,
+                              int gathered, int fidelity, int robust, float delta, float *res_dev, void *stream);
+int tomo_sino_robust(float *res_dev, size_t count, int robust, float delta, void *stream);
 
 /* ---------------------------------------------------------------- ring-artefact data terms (BASELINE configs[4])
  * Not in this reference version (supp/dicts.py:85-88 accepts LS / PWLS / KL only); they are documented for its removed

@@ -386,8 +386,27 @@ def grad_data_term(P, x, b_sub, subset, fidelity="LS", w_sub=None):
     return P.bp(res.astype(np.float32, copy=False), subset)
 
 
+def robust_weight(res, huber=None, studentst=None):
+    """Huber / Student's-t re-weighting of a data residual -- the data terms of the reference's removed RecToolsIR class
+    (_data_["huber_threshold"], _data_["studentst_threshold"]: Demos/methods_IR_legacy/DemoFISTA_artifacts2D.py:197,263,
+    307,348; listed in docs/source/introduction/about.rst:38).  NOT in this reference version: formula-level, PARITY UNPINNED.
+    Huber: gradient of the Huber function, res * (delta/|res|) where |res| > delta.  Student's t [KAZ1_2017]: gradient of
+    log(delta^2 + res^2), res * 2/(delta^2 + res^2).  float32 throughout."""
+    res = np.asarray(res, dtype=np.float32)
+    if huber is not None:
+        d = np.float32(huber)
+        mult = np.ones_like(res)
+        big = np.abs(res) > d
+        mult[big] = d / np.abs(res[big])
+        res = mult * res
+    if studentst is not None:
+        d = np.float32(studentst)
+        res = (np.float32(2.0) / (d * d + res * res)) * res
+    return res.astype(np.float32)
+
+
 def fista(P: Projector, b, iterations, lipschitz_const, nonnegativity=False, reg=None, fidelity="LS", x0=None,
-          ring=None, beta_swls=0.1):
+          ring=None, beta_swls=0.1, huber=None, studentst=None):
     """methodsIR_CuPy.py:438-475 (b already padded, canonical [detY, angles, detX] layout).
 
     Ring-artefact data terms (NOT in this reference version -- supp/dicts.py:85-88 knows LS / PWLS / KL only; parity for
@@ -399,7 +418,9 @@ def fista(P: Projector, b, iterations, lipschitz_const, nonnegativity=False, reg
         r = r_x - (1/L) * sum_angles(res) (float32, ascending angle order); PWLS weights are applied to res afterwards;
         after the image update r = soft(r, l) and r_x = r + ((t_old - 1)/t) (r - r_old).
       * ``fidelity = "SWLS"``: stripe-weighted least squares, W_s = W - W 1 (1^T W 1 + beta)^-1 1^T W per detector pixel:
-        res_a = w_a res_a - w_a (sum_a w_a res_a)/(sum_a w_a + beta), sums over the sub-iteration's angles."""
+        res_a = w_a res_a - w_a (sum_a w_a res_a)/(sum_a w_a + beta), sums over the sub-iteration's angles.
+      * ``huber`` / ``studentst``: threshold of the robust re-weighting (robust_weight above) applied to the residual
+        last, i.e. after the PWLS weights, the ring offsets and the SWLS weighting."""
     b = np.ascontiguousarray(b, dtype=np.float32)
     w = pwls_weights(b) if fidelity in ("PWLS", "SWLS") else None
     L_inv = np.float32(1.0 / lipschitz_const)
@@ -437,7 +458,15 @@ def fista(P: Projector, b, iterations, lipschitz_const, nonnegativity=False, reg
                         ws = ws + w_s[:, a, :]
                     q = wr / (ws + np.float32(beta_swls))
                     res = w_s * res - w_s * q[:, None, :]
+                if huber is not None or studentst is not None:
+                    res = robust_weight(res, huber, studentst)
                 grad = P.bp(np.ascontiguousarray(res, dtype=np.float32), sub)
+            elif huber is not None or studentst is not None:
+                # LS / PWLS residual of data_fidelities.py:28-34, re-weighted, then A^T
+                res = P.fp(X_t, sub) - b_s
+                if fidelity == "PWLS":
+                    res = res * w_s
+                grad = P.bp(np.ascontiguousarray(robust_weight(res, huber, studentst)), sub)
             else:
                 grad = grad_data_term(P, X_t, b_s, sub, fidelity, w_s)
             X = X_t - L_inv * grad

@@ -16,9 +16,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtomo_mi355x.so")
 
 OK, E_INVALID, E_RUNTIME, E_NOMEM, E_NODEVICE = 0, 1, 2, 3, 4
-ABI_VERSION = 5  # TOMO_ABI_VERSION of include/tomo_mi355x.h (tests/test_host_logic.py keeps the two in step)
+ABI_VERSION = 6  # TOMO_ABI_VERSION of include/tomo_mi355x.h (tests/test_host_logic.py keeps the two in step)
 FLAG_LERP8 = 1
 FID = {"LS": 0, "PWLS": 1, "KL": 2, "RATIO": 3}
+ROBUST = {None: 0, "huber": 1, "studentst": 2}   # TOMO_ROBUST_* of include/tomo_mi355x.h
 RESIDUAL_LAYOUT = {"planar": 0, "zquad": 1}   # TOMO_RESIDUAL_* of include/tomo_mi355x.h
 
 
@@ -47,6 +48,8 @@ SIGNATURES = {
     "tomo_fp3d": (_i, [_vp, _i, _vp, _vp, _vp]),
     "tomo_bp3d": (_i, [_vp, _i, _vp, _vp, _vp]),
     "tomo_fp3d_residual": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "tomo_fp3d_residual_robust": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
+    "tomo_sino_robust": (_i, [_vp, _sz, _i, _f, _vp]),
     "tomo_fp3d_residual_ring": (_i, [_vp, _i, _vp, _vp, _vp, _f, _vp, _vp]),
     "tomo_ring_gh_reduce": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp]),
     "tomo_swls_apply": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -35,8 +35,11 @@ typedef __attribute__((address_space(3))) void *bb_lds_ptr;
 // (s_nop: one wait state between an SALU write of M0 and an LDS-DMA that reads it.)
 __device__ __forceinline__ void bb_dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_addr, int voff)
 {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");  // (M0 is a reserved register: the compiler sets it itself right before each of ITS
-                                                                               //  uses -- none in this kernel -- and keeps nothing in it)
+    // M0 cannot be listed as a clobber: to this compiler it is a RESERVED register ("inline asm clobber list contains reserved
+    // registers: m0"), i.e. it never allocates it or keeps a value live in it -- it writes M0 itself immediately before each of
+    // its own M0-reading instructions (LDS-direct, indirect register indexing; none in this kernel), so this statement cannot
+    // break a live value; tests/test_gpu_parity.py pins the kernel's output bit for bit should a compiler change that.
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
 }
 
 // ZQ (round 5): the sinogram is the PRIVATE residual layout [z/4][angle][u][4] that tomo_fp3d_residual leaves on a context
@@ -133,7 +136,9 @@ __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
             (int)(((unsigned)min((zlim >> 2) + 1, BB_ZQ) * zstride - (unsigned)a0 * (unsigned)a.nu) << 4), 0x00020000);
 #pragma unroll
         for (int m = 0; m < BB_ITEMS; ++m) {
-            const int u = umin_s[buf][it_aa[m]] + it_j[m];
+            // (the items of the partial last round beyond BB_NITEMS belong to an angle slot >= BB_AB: nothing is issued for them,
+            // and their window read stays inside the table)
+            const int u = umin_s[buf][min(it_aa[m], BB_AB - 1)] + it_j[m];
             unsigned off = it_off[m] + (unsigned)min(max(u, 0), a.nu - 1);
             if (it_aa[m] > amax) off -= (unsigned)(it_aa[m] - amax) * (unsigned)a.nu;
             const int boff = (u >= 0 && u < a.nu) ? (int)(off << 4) : (int)0x80000000;

@@ -16,6 +16,7 @@ struct FpTiledArgs {
     const float *src;        // volume with the interpolation axis contiguous ([nz][n][n])
     const tomo_angle_t *tab; // subset table
     const int *order;        // subset-local angle indices of this stepping class
+    const int *mult;         // per entry of `order`: odd lane -> pixel multiplier of the whole-row form (null: 1), see fp_lane_mult
     int n_class;             // angles in the class
     int nz, n, nu, na, na_full;
     float *out;
@@ -98,17 +99,26 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
 #else
     const int lane_pix = fp_lane_pixel(lane);
 #endif
-    const int iu = u0 + (tid - lane) + lane_pix;
+    const int t_log = (tid - lane) + lane_pix;   // the thread's logical position in the detector tile
+    const int iu = u0 + t_log;                   // ... and the pixel it STORES (epilogue)
     const int n = a.n;
     const int ng = min(A, a.n_class - g * A);   // angles in this group (uniform)
     const int *ord = a.order + g * A;
+    // Per-angle lane -> pixel permutation (round 6, whole-row form only): for angle i the thread marches pixel
+    // (m_i * t_log) mod bt, m_i odd and coprime with bt, chosen per angle so that the 16 slots a ds_read_b128 service group
+    // samples -- m_i / |cos| apart instead of 1 / |cos| -- fall into as many different bank rows as possible
+    // (fp_lane_mult; docs/kernels/fp.md).  Free inside the march: a thread's accumulators are independent per angle.  The
+    // epilogue hands every value back to the thread that stores it through LDS.
+    const bool perm = (BT == 1024) && a.mult != nullptr;   // uniform
+    const int *mul = perm ? a.mult + g * A : nullptr;
 
     const float half_n = 0.5f * (float)n - 0.5f, half_u = 0.5f * (float)a.nu - 0.5f, nf = (float)n;
     float offs[A], slope[A], acc[A][4];
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         const tomo_angle_t t = a.tab[ord[i < ng ? i : 0]];
-        const float s = ((float)iu - half_u) + t.cor;
+        const int iu_m = perm ? u0 + (mul[i < ng ? i : 0] * t_log) % bt : iu;   // the pixel this thread MARCHES for angle i
+        const float s = ((float)iu_m - half_u) + t.cor;
         offs[i] = fmaf(s, t.inv, half_n);
         slope[i] = t.slope;
 #pragma unroll
@@ -230,6 +240,20 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
             }
         }
     }
+    if (BT == 1024 && perm) {
+        // un-permute: angle by angle through two LDS rows of bt float4 (the tiles are free now), one barrier per angle;
+        // afterwards acc[i] holds the four slices of the pixel this thread stores and the epilogue below is the usual one
+        float4 *stage = tile0;
+        __syncthreads();   // every wave is past its last tile read
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            float4 *row = stage + (i & 1) * bt;
+            row[(mul[i < ng ? i : 0] * t_log) % bt] = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+            __syncthreads();
+            const float4 v = row[t_log];
+            acc[i][0] = v.x; acc[i][1] = v.y; acc[i][2] = v.z; acc[i][3] = v.w;
+        }
+    }
     if (iu >= a.nu) return;
     // (guards instead of `break`s: with 16 angles the unroller gives up on an early-exit loop and the accumulator array,
     // indexed by a run-time `i`, lands in scratch memory)
@@ -254,6 +278,57 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
                 reinterpret_cast<float4 *>(a.out)[((size_t)zb * a.na + k_a) * a.nu + iu] = make_float4(v4[0], v4[1], v4[2], v4[3]);
         }
     }
+}
+
+// ---- per-angle lane -> pixel multiplier of the whole-row form (host).  Bank model of one ds_read_b128 service group: its 16
+// lanes hold 16 consecutive logical positions t, i.e. pixels m*t mod bt, i.e. LDS slots floor(x0 + s*pixel) with s = 1/|cos|
+// (|inv| of the angle record) in [1, 1.4143]; the LDS serves the group in as many cycles as the fullest of its 16 bank rows
+// (slot mod 16) holds DIFFERENT slots.  m = 1 spans up to 22 slots (two-way conflicts: 1.5-2.0 cycles at 20-45 degrees), the
+// best odd m < 64 per angle 1.5-1.7.  Measured on the kernel's own loop: tools/probes/fp_combo_probe.hip,
+// profiles/r6_fp_combo_probe.txt (sampling loop x 1.09 alone, x 1.215 together with 8 slices per thread).
+static double fp_bank_model(double s, int m, int bt)
+{
+    double total = 0.0;
+    int cnt = 0;
+    for (int ph = 0; ph < 8; ++ph) {
+        const double x0 = 3.0 + ph * 0.91;
+        for (int t0 = 0; t0 + 16 <= bt; t0 += 16 * 5) {   // every fifth service group
+            int distinct[16], nd = 0, rows[16] = {0};
+            for (int j = 0; j < 16; ++j) {
+                const int slot = (int)std::floor(x0 + s * (double)((m * (t0 + j)) % bt));
+                bool seen = false;
+                for (int q = 0; q < nd; ++q) seen |= distinct[q] == slot;   // same slot: one broadcast
+                if (!seen) { distinct[nd++] = slot; ++rows[slot & 15]; }
+            }
+            int worst = 1;
+            for (int r = 0; r < 16; ++r) worst = std::max(worst, rows[r]);
+            total += worst;
+            ++cnt;
+        }
+    }
+    return cnt ? total / cnt : 1.0;
+}
+
+// multiplier for stride s and tile width bt, memoised on a 1/512 grid of s (the model is smooth at that scale and a
+// context asks for up to a few thousand angles)
+static int fp_lane_mult(double s, int bt)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, int> memo;
+    const int key = (int)std::lround((std::min(std::max(s, 1.0), 1.4143) - 1.0) * 512.0);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = memo.find({bt, key});
+    if (it != memo.end()) return it->second;
+    const double sq = 1.0 + key / 512.0;
+    int best_m = 1;
+    double best = fp_bank_model(sq, 1, bt);
+    for (int m = 3; m < 64; m += 2) {
+        if (std::gcd(m, bt) != 1) continue;   // m*t mod bt must be a bijection (bt = 896 = 2^7 * 7 rules out 7, 21, ...)
+        const double c = fp_bank_model(sq, m, bt);
+        if (c < best - 1e-3) { best = c; best_m = m; }
+    }
+    memo[{bt, key}] = best_m;
+    return best_m;
 }
 
 // Upper bound (host, same float arithmetic as the kernel) of the staged window width over all groups / tiles / rows.

@@ -512,6 +512,33 @@ extern "C" int tomo_sino_add_ring(float *res_dev, const float *ring_dev, float r
     return TOMO_OK;
 }
 
+// Huber / Student's-t re-weighting of a residual that was NOT formed by tomo_fp3d_residual_robust's epilogue (the ring-term and
+// vertical-CoR paths); element-wise, so either residual layout works (the padding of a quad-interleaved one is 0 -> 0)
+__global__ __launch_bounds__(256) void sino_robust_kernel(float *__restrict__ res, size_t count, int mode, float delta)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        float r = res[i];
+        if (mode == TOMO_ROBUST_HUBER) {
+            const float ar = fabsf(r);
+            if (ar > delta) r = (delta / ar) * r;
+        } else {
+            r = (2.0f / (delta * delta + r * r)) * r;
+        }
+        res[i] = r;
+    }
+}
+
+extern "C" int tomo_sino_robust(float *res_dev, size_t count, int robust, float delta, void *stream)
+{
+    TOMO_REQUIRE(res_dev != nullptr || count == 0, "NULL residual pointer");
+    TOMO_REQUIRE(robust == TOMO_ROBUST_HUBER || robust == TOMO_ROBUST_STUDENTST, "unknown robust mode %d", robust);
+    TOMO_REQUIRE(delta > 0.0f, "the Huber / Student's-t threshold must be positive");
+    if (count == 0) return TOMO_OK;
+    sino_robust_kernel<<<(unsigned)std::min<size_t>((count + 255) / 256, 8192), 256, 0, as_stream(stream)>>>(res_dev, count, robust, delta);
+    TOMO_LAUNCH_CHECK();
+    return TOMO_OK;
+}
+
 extern "C" int tomo_ring_gh_reduce(float *res_dev, const float *w_full_dev, const int *src_dev, int nz, int na_s, int na_full,
                                    int nu, const float *rx_dev, float l_inv, float *r_out_dev, void *stream)
 {

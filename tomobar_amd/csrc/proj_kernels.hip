@@ -23,6 +23,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <map>
+#include <mutex>
+#include <numeric>
 #include <string>
 #include <type_traits>
 
@@ -334,7 +337,13 @@ __global__ __launch_bounds__(256) void sino_to_quad_kernel(const float *__restri
 }
 
 constexpr size_t BP_RELAY_MAX_BYTES = (size_t)16 << 30;  // largest sinogram tomo_bp3d* re-lays into its scratch arena
-std::atomic<size_t> g_bp_relay_refused{~(size_t)0};      // smallest relay scratch the device could NOT provide (never asked again)
+// Smallest relay scratch a DEVICE could not provide (out of memory only): requests that large go straight to the planar staging
+// instead of failing a hipMalloc per call.  Not for ever: another tenant's placement search or a framework's caching allocator
+// may have held the memory for a moment, so every BP_RELAY_RETRY-th refused call asks again and tomo_release_scratch(device)
+// forgets the refusal (tomo_bp_relay_reset).
+constexpr int BP_RELAY_DEVICES = 64, BP_RELAY_RETRY = 64;
+struct bp_relay_state { std::atomic<size_t> refused{~(size_t)0}; std::atomic<unsigned> skipped{0}; };
+bp_relay_state g_bp_relay[BP_RELAY_DEVICES];
 
 template <int EPI>
 int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
@@ -362,10 +371,21 @@ int bp_launch(BpArgs a, bool lerp8, hipStream_t st)
     if (g_variant_bp == 0 && !a.zquad && (long)a.na * a.nu < (1L << 25) && a.na > 0) {
         const size_t row = (size_t)a.na * a.nu, nq = (size_t)ceil_div(a.nz, 4), bytes = nq * row * 16;
         void *q = nullptr;
-        bool have = bytes <= BP_RELAY_MAX_BYTES && nq <= 65535 && bytes < g_bp_relay_refused.load();
-        if (have && tomo_arena_get(a.device, st, ARENA_BPQ, bytes, &q) != TOMO_OK) {
-            g_bp_relay_refused.store(bytes);   // out of memory: the planar staging runs, now and for every request this large
-            have = false;
+        bp_relay_state &rs = g_bp_relay[a.device >= 0 && a.device < BP_RELAY_DEVICES ? a.device : 0];
+        bool have = bytes <= BP_RELAY_MAX_BYTES && nq <= 65535;
+        if (have && bytes >= rs.refused.load() && (rs.skipped.fetch_add(1) + 1) % BP_RELAY_RETRY != 0) have = false;
+        if (have) {
+            const int rc = tomo_arena_get(a.device, st, ARENA_BPQ, bytes, &q);
+            if (rc == TOMO_E_NOMEM) {   // the planar staging runs, now and for the next requests this large on this device
+                rs.refused.store(std::min(rs.refused.load(), bytes));
+                tomo_warn_once("bp_relay", "back projection: no memory for the quad-interleaved relay of a planar sinogram, "
+                                           "running the planar staging (slower; asked again every 64th call and after tomo_release_scratch)");
+                have = false;
+            } else if (rc != TOMO_OK) {
+                return rc;   // a caller error or a runtime failure is reported, not papered over
+            } else {
+                rs.refused.store(~(size_t)0);
+            }
         }
         if (have) {
             sino_to_quad_kernel<<<dim3((unsigned)((row + 255) / 256), (unsigned)nq), 256, 0, st>>>(a.sino, (float4 *)q, a.nz, row);
@@ -728,10 +748,38 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 smem_w = (size_t)kc_w * wp * 16 + tab_w;
             }
             if (!(pays && passes_w <= 5 && smem_w <= 160 * 1024)) return 0;
+            // per-angle lane -> pixel multipliers (round 6), built once per context for this tile width; the un-permute of
+            // the epilogue needs two LDS rows of bt float4 inside the tile area
+            const int *mult_d = nullptr;
+#ifndef TOMO_FP_NO_LANE_MULT   // A/B builds only (tools/run_ab.sh)
+            // measured A/B (profiles/r6_fp_lane_multiplier_ab.txt): x 1.024 at 1024 pixels (configs[2]), x 1.047 at 896 (configs[4]
+            // share), 0.97-0.99 at 256-640 pixels where the un-permute of the epilogue is not paid back: from 768 pixels up only
+            constexpr int FP_MULT_MIN_BT = 768;
+            if (bt >= FP_MULT_MIN_BT && (size_t)2 * bt * 16 <= smem_w - tab_w && g_variant_fp != 4) {
+                if (ctx->dev_fp_mult == nullptr || ctx->fp_mult_bt != bt) {
+                    std::vector<int> mh(ctx->host_fp_order.size(), 1);
+                    for (const tomo_subset &ss : ctx->subsets)
+                        for (int i = 0, ne = ss.n_class[0] + ss.n_class[1] + ss.n_class[2] + ss.n_class[3]; i < ne; ++i) {
+                            const tomo_angle_t &rec = ctx->host_table[ss.table_offset + ctx->host_fp_order[ss.table_offset + i]];
+                            mh[ss.table_offset + i] = fp_lane_mult(std::fabs((double)rec.inv), bt);
+                        }
+                    // (this lambda reports errors as -1, not as a TOMO_E_* code)
+                    if (ctx->dev_fp_mult == nullptr) {
+                        if (hipMalloc((void **)&ctx->dev_fp_mult, std::max<size_t>(mh.size(), 1) * sizeof(int)) != hipSuccess) return -1;
+                    } else if (hipDeviceSynchronize() != hipSuccess) {   // a launch in flight may still read the old table
+                        return -1;
+                    }
+                    if (hipMemcpy(ctx->dev_fp_mult, mh.data(), mh.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
+                    ctx->fp_mult_bt = bt;
+                }
+                mult_d = ctx->dev_fp_mult + off_d;
+            }
+#endif
             FpTiledArgs t;
             t.src = d ? a.volT : a.vol;
             t.tab = a.tab;
             t.order = ctx->dev_fp_order + off_d;
+            t.mult = mult_d;
             t.n_class = nc;
             t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
             t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
@@ -795,6 +843,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
             t.src = (c >> 1) ? a.volT : a.vol;
             t.tab = a.tab;
             t.order = ctx->dev_fp_order + off_c;
+            t.mult = nullptr;
             t.n_class = nc;
             t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
             t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
@@ -826,7 +875,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
         {
             size_t axis_off = s.table_offset;
             const int nut = ceil_div(a.nu, 256);
-            for (int d = 0; d < 2 && (g_variant_fp == 0 || g_variant_fp == 3) && a.nu >= FP_WIDE_MIN_NU; ++d) {
+            for (int d = 0; d < 2 && (g_variant_fp == 0 || g_variant_fp == 3 || g_variant_fp == 4) && a.nu >= FP_WIDE_MIN_NU; ++d) {
                 const int nc0 = s.n_class[2 * d], nc1 = s.n_class[2 * d + 1], nc = nc0 + nc1;
                 const size_t off_d = axis_off;
                 axis_off += nc;
@@ -841,7 +890,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
 #ifdef TOMO_FP_NO_DENSE16   // A/B builds only (tools/run_ab.sh)
                     take = false;
 #endif
-                    if (take && g_variant_fp == 0) {
+                    if (take && (g_variant_fp == 0 || g_variant_fp == 4)) {
                         double rows = 0.0;
                         if (a.nu <= 1024) {
                             if (s.wbound_wide[2 * d] < 0)
@@ -904,6 +953,7 @@ int fp_run(tomo_ctx *ctx, int subset, const float *vol, const float *b, const fl
                 t.src = (c >> 1) ? a.volT : a.vol;
                 t.tab = a.tab;
                 t.order = ctx->dev_fp_order + order_off;
+                t.mult = nullptr;
                 t.n_class = nc;
                 t.nz = a.nz; t.n = a.n; t.nu = a.nu; t.na = a.na; t.na_full = a.na_full;
                 t.out = out; t.b = b; t.w = w; t.fidelity = fidelity; t.gathered = gathered;
@@ -990,6 +1040,13 @@ int bp_prepare(tomo_ctx *ctx, int subset, const float *sino, BpArgs &a)
 }
 
 }  // namespace
+
+void tomo_bp_relay_reset(int device)
+{
+    if (device < 0 || device >= BP_RELAY_DEVICES) return;
+    g_bp_relay[device].refused.store(~(size_t)0);
+    g_bp_relay[device].skipped.store(0);
+}
 
 // ------------------------------------------------------------------------------------------ C-ABI
 extern "C" int tomo_fp3d(tomo_ctx *ctx, int subset, const float *vol_dev, float *sino_dev, void *stream)

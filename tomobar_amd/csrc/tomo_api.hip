@@ -61,7 +61,7 @@ extern "C" int tomo_set_variant(const char *kernel, int variant)
     int *slot = nullptr;
     bool ok = false;
     if (k == "bp") { slot = &g_variant_bp; ok = allowed({0}, {1, 2, 3}); }
-    else if (k == "fp") { slot = &g_variant_fp; ok = allowed({0}, {1, 2, 3}); }
+    else if (k == "fp") { slot = &g_variant_fp; ok = allowed({0}, {1, 2, 3, 4}); }   // 4 = whole-row form without the per-angle lane multipliers (A/B)
     else if (k == "pdtv") { slot = &g_variant_pdtv; ok = allowed({0, 22}, {1, 2, 3, 21, 31, 32}); }
     else if (k == "roftv") { slot = &g_variant_roftv; ok = allowed({0}, {1, 2, 3, 4}); }
 #if TOMO_DEV
@@ -195,6 +195,7 @@ extern "C" int tomo_ctx_destroy(tomo_ctx *ctx)
     tomo_device_guard guard(ctx->device);
     if (ctx->dev_table) (void)hipFree(ctx->dev_table);
     if (ctx->dev_fp_order) (void)hipFree(ctx->dev_fp_order);
+    if (ctx->dev_fp_mult) (void)hipFree(ctx->dev_fp_mult);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     delete ctx;
     return TOMO_OK;
@@ -212,7 +213,10 @@ extern "C" int tomo_ctx_release_scratch(tomo_ctx *ctx)
         ctx->scratch = nullptr;
         ctx->scratch_bytes = 0;
     }
-    return TOMO_OK;
+    // the back projector's relay block (a planar sinogram re-laid quad-interleaved: as large as the sinogram, e.g. 3.7 GB for
+    // FBP of 1024^3 x 900) lives in the device's arena, outside the caller's allocator: a context that gives its scratch back
+    // gives that back as well (it is re-made on the next tomo_bp3d of any context on this device)
+    return tomo_arena_release_slot(ctx->device, ARENA_BPQ);
 }
 
 void tomo_warn_once(const char *key, const char *msg)
@@ -468,9 +472,11 @@ int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void 
     }
     // grow outside the map's mutex: the stream's own work is the only user of this arena (two host threads driving ONE
     // stream's scratch at once is a caller error, detected below)
-    if (old) {
-        TOMO_HIP(hipStreamSynchronize(stream));
-        TOMO_HIP(hipFree(old));
+    if (old) {   // the old block is released whatever happens next (the map no longer knows it)
+        const hipError_t es = hipStreamSynchronize(stream);
+        const hipError_t ef = hipFree(old);
+        TOMO_HIP(es);
+        TOMO_HIP(ef);
     }
     void *p = nullptr;
     // (the back projector's relay scratch is an optimisation it can do without: one attempt, no waiting)
@@ -503,10 +509,28 @@ extern "C" int tomo_placed_scratch(int device, int slot, size_t bytes, void *str
     return tomo_arena_get(device, as_stream(stream), ARENA_CALLER0 + slot, bytes, out_dev, true);
 }
 
+int tomo_arena_release_slot(int device, int slot)
+{
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    bool any = false;
+    for (auto it = g_arenas.begin(); it != g_arenas.end();) {
+        if (it->first.device == device && it->first.slot == slot && it->second.ptr) {
+            tomo_device_guard g(device);
+            if (!any) { TOMO_HIP(hipDeviceSynchronize()); any = true; }
+            TOMO_HIP(hipFree(it->second.ptr));
+            it = g_arenas.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return TOMO_OK;
+}
+
 extern "C" int tomo_release_scratch(int device)
 {
     tomo_fourier_cache_release(device);
     tomo_fbp_cache_release(device);
+    tomo_bp_relay_reset(device);
     std::lock_guard<std::mutex> lk(g_arena_mu);
     bool any = false;
     for (auto it = g_arenas.begin(); it != g_arenas.end();) {

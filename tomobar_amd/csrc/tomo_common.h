@@ -60,6 +60,8 @@ struct tomo_ctx {
     tomo_angle_t *dev_table = nullptr;
     std::vector<int> host_fp_order;           // same indexing as host_table
     int *dev_fp_order = nullptr;
+    int *dev_fp_mult = nullptr;               // whole-row FP form: lane -> pixel multiplier per entry of the order table (built on first use)
+    int fp_mult_bt = 0;                       // ... for this tile width
     void *scratch = nullptr;                  // grow-only (FP: in-plane transposed volume)
     size_t scratch_bytes = 0;
     const float *volT_of = nullptr;           // volume whose transposed copy `scratch` holds (tomo_momentum_transposed)
@@ -96,6 +98,8 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 // grow-only scratch arena per (device, stream, slot) (tomo_release_scratch frees a device's arenas)
 enum { ARENA_MAIN = 0, ARENA_REDUCE = 1, ARENA_TV = 2 /* placed: the TV operators' work arrays */, ARENA_BPQ = 3 /* a planar sinogram re-laid quad-interleaved for the back projector */, ARENA_CALLER0 = 16 /* .. +7: tomo_placed_scratch (placed) */ };
 int tomo_arena_get(int device, hipStream_t stream, int slot, size_t bytes, void **out, bool place = false);  // place: see tomo_api.hip
+int tomo_arena_release_slot(int device, int slot);  // frees the arenas of one slot on a device (all streams)
+void tomo_bp_relay_reset(int device);         // forget that the back projector's relay scratch was refused (proj_kernels.hip)
 void tomo_fourier_cache_release(int device);  // cached hipFFT plans of fourier_inv.hip
 void tomo_fbp_cache_release(int device);      // cached hipFFT plans / filter tables of fbp_filter.hip
 
@@ -105,7 +109,7 @@ void tomo_fbp_cache_release(int device);      // cached hipFFT plans / filter ta
 //                          1e-5).  No measurement switches are compiled in: g_probe is the constant 0 and every
 //                          `probe &` test folds away.
 //   libtomo_mi355x_dev.so  (-DTOMO_DEV_VARIANTS; tests and tools/ only): the independent implementations and A/B builds
-//                          (bp 1/2, fp 1/2/3, pdtv 1/2/3/21, roftv 1/2/3/4) and the "probe" bits of tools/*_probe.py.
+//                          (bp 1/2, fp 1/2/3/4, pdtv 1/2/3/21, roftv 1/2/3/4) and the "probe" bits of tools/*_probe.py.
 extern thread_local int g_variant_bp, g_variant_fp, g_variant_pdtv, g_variant_roftv;
 #ifdef TOMO_DEV_VARIANTS
 #define TOMO_DEV 1

@@ -196,6 +196,12 @@ class RecToolsIRCuPy:
         ring_lambda = d.get("ringGH_lambda")
         use_ring = ring_lambda is not None
         use_swls = fid == "SWLS"
+        # Huber / Student's-t data terms: the (weighted) residual is re-weighted before the back projection
+        robust = None
+        if d.get("huber_threshold") is not None:
+            robust = ("huber", float32(d["huber_threshold"]))
+        elif d.get("studentst_threshold") is not None:
+            robust = ("studentst", float32(d["studentst_threshold"]))
         if use_ring:
             ring_acc = float32(d["ringGH_accelerate"])
             r_shape = (A.nz, A.nu)
@@ -230,11 +236,15 @@ class RecToolsIRCuPy:
                         # res = (A_s X_t - b_s) + accelerate * r_x ;  r = r_x - (1/L) sum_angles res ;  then the PWLS weights
                         A.residual_ring(X_t, b, r_x, ring_acc, sub, res[sub])
                         A.ring_reduce(res[sub], w if fid == "PWLS" else None, r_x, L_inv, sub, r_cur)
+                        if robust is not None:
+                            A.robust_apply(res[sub], *robust)
                     elif use_swls:
                         A.residual(X_t, b, None, "LS", sub, res[sub])
                         A.swls_apply(res[sub], w, float32(d["beta_SWLS"]), sub)
+                        if robust is not None:
+                            A.robust_apply(res[sub], *robust)
                     else:
-                        A.residual(X_t, b, w, fid, sub, res[sub])
+                        A.residual(X_t, b, w, fid, sub, res[sub], robust=robust)
                     t = float32((float32(1.0) + np.sqrt(float32(1.0) + float32(4.0) * t * t)) * float32(0.5))
                     beta = float32((t_old - float32(1.0)) / t)
                     if not has_prox:

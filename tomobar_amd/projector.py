@@ -281,9 +281,20 @@ class HipTools3D:
         return res.permute(0, 3, 1, 2).reshape(-1, res.shape[1], res.shape[2])[: self.nz].contiguous()
 
     # fused forms used by the FISTA / ADMM drivers (buffers validated by the drivers)
-    def residual(self, vol, b, w, fidelity: str, os_index, out, gathered: int = 0):
+    def residual(self, vol, b, w, fidelity: str, os_index, out, gathered: int = 0, robust=None):
         """out = w_s*(A_s vol - b_s) (LS/PWLS) or 1 - b_s/max(A_s vol, 1e-8) (KL); ``gathered`` bit0/bit1: b / w is
-        already the subset's array instead of the full sinogram."""
+        already the subset's array instead of the full sinogram.  ``robust`` = ("huber" | "studentst", threshold):
+        the Huber / Student's-t re-weighting of the residual in the same epilogue (include/tomo_mi355x.h)."""
+        if robust is not None:
+            mode, delta = robust
+            if self._vshift is not None:
+                self.residual(vol, b, w, fidelity, os_index, out, gathered)
+                return self.robust_apply(out, mode, delta)
+            with torch.cuda.device(self._device):
+                self._chk(self._lib.tomo_fp3d_residual_robust(self._ctx, self._sub(os_index), ops.ptr(vol), ops.ptr(b),
+                                                          ops.ptr(w), int(gathered), L.FID[fidelity], L.ROBUST[mode],
+                                                          float(delta), ops.ptr(out), ops.stream_ptr(vol)))
+            return out
         if self._vshift is not None:
             ax = self.forward(vol, os_index)
             src = self._src_table(os_index)
@@ -334,6 +345,12 @@ class HipTools3D:
         with torch.cuda.device(self._device):
             self._chk(self._lib.tomo_swls_apply(ops.ptr(res), ops.ptr(w), ops.ptr(src), self.nz, int(src.numel()), self.na,
                                             self.nu, float(beta), ops.stream_ptr(res)))
+
+    def robust_apply(self, res, mode: str, delta):
+        """res <- Huber / Student's-t re-weighting of res, in place (any residual layout)."""
+        with torch.cuda.device(self._device):
+            self._chk(self._lib.tomo_sino_robust(ops.ptr(res), res.numel(), L.ROBUST[mode], float(delta), ops.stream_ptr(res)))
+        return res
 
     def ring_update(self, r, r_old, r_x, lam, beta):
         with torch.cuda.device(self._device):

@@ -68,6 +68,21 @@ def dicts_check(self, _data_: dict, _algorithm_: Optional[dict] = None, _regular
     if _data_["ringGH_lambda"] is not None and method_run != "FISTA":
         raise ValueError("the Group-Huber ring term (ringGH_lambda) is available in FISTA only")
 
+    # Huber / Student's-t data terms (outlier-robust re-weighting of the residual): keys of the removed RecToolsIR class as
+    # well (Demos/methods_IR_legacy/DemoFISTA_artifacts2D.py:197,263,307,348; docs/source/introduction/about.rst:38)
+    _data_.setdefault("huber_threshold", None)
+    _data_.setdefault("studentst_threshold", None)
+    for key in ("huber_threshold", "studentst_threshold"):
+        if _data_[key] is not None:
+            if method_run != "FISTA":
+                raise ValueError(f"the robust data term ({key}) is available in FISTA only")
+            if _data_["data_fidelity"] == "KL":
+                raise ValueError(f"the robust data term ({key}) combines with the 'LS', 'PWLS' and 'SWLS' data fidelities only")
+            if not float(_data_[key]) > 0.0:
+                raise ValueError(f"_data_['{key}'] must be a positive threshold")
+    if _data_["huber_threshold"] is not None and _data_["studentst_threshold"] is not None:
+        raise ValueError("give either 'huber_threshold' or 'studentst_threshold', not both")
+
     if self.OS_number > 1 and method_run in _NO_OS_METHODS:
         raise NameError(
             "There is no ordered-subsets implementation for this reconstruction method, please set OS_number=None")
