@@ -26,9 +26,9 @@ scalar reductions.
                     problem -- `--strong --config cfg5` is the north-star workload (2560^2 x 2160, 1800 angles).
 Per-rank exchange statistics (messages, bytes, host time posting / waiting, compute-stream stall) are in `halo`.
 
-One JSON line is printed by rank 0 (see the contract in the task statement) with two extra objects: `roofline`
-(dominant kernel by time in the timed region, measured with HIP events on the launch stream by the library itself)
-and `cpu_baseline` (the CPU oracle, oracle/tomo_oracle.c, on the host cores for a z-subsample of the SAME sinogram).
+One JSON line is printed by rank 0 (see the contract in the task statement) with extra objects: `roofline`
+(dominant kernel by time in the timed region, measured with HIP events on the launch stream by the library itself),
+`roofline_bp` / `roofline_fp` (the two projectors whatever dominates) and `cpu_baseline` (the CPU oracle, oracle/tomo_oracle.c, on the host cores for a z-subsample of the SAME sinogram).
 """
 import argparse
 import ctypes as C
@@ -118,10 +118,12 @@ def parse():
                    help="PD_TV float32 duals with the reference's rounding sequence (tomo_set_variant('pdtv', 22): bit-identical "
                         "to the oracle, +5 ... +16 %% per launch; the default is within 1e-5); the workload string says so")
     p.add_argument("--north-star", action="store_true",
-                   help="N > 1 only: after the headline workload also run strong scaling of BASELINE configs[4] (when every "
-                        "rank's share fits) and report it as an extra `north_star` block; BENCH_NORTH_STAR=1 acts like the flag. "
-                        "Off by default: a second full workload multiplies the wall time of a driver that only varies --gpus")
-    p.add_argument("--no-north-star", action="store_true", help="accepted for compatibility (the block is opt-in now)")
+                   help="N > 1: after the headline workload also run strong scaling of BASELINE configs[4] as a SUPERVISED CHILD JOB "
+                        "(a second torch.distributed.run started by rank 0 once every rank has finished and the headline is on "
+                        "stderr; hard wall-clock limit BENCH_NORTH_STAR_TIMEOUT, default 900 s) and report it as an extra "
+                        "`north_star` block.  On by default from 4 ranks on real GPUs (where every rank's share fits); "
+                        "BENCH_NORTH_STAR=1 acts like the flag, BENCH_NORTH_STAR=0 / --no-north-star switch it off")
+    p.add_argument("--no-north-star", action="store_true", help="never run the north-star child job")
     if len(sys.argv) == 1 and "TOMO_BENCH_ARGV" in os.environ and "RANK" in os.environ:  # rank started by self_launch()
         args = p.parse_args(json.loads(os.environ["TOMO_BENCH_ARGV"]))
     else:
@@ -136,6 +138,8 @@ def parse():
         args.strong = True
     if os.environ.get("BENCH_NORTH_STAR", "0") not in ("", "0") or os.environ.get("BENCH_NORTH_STAR_TEST", "0") not in ("", "0"):
         args.north_star = True
+    if os.environ.get("BENCH_NORTH_STAR", "") == "0":
+        args.no_north_star = True
     if os.environ.get("BENCH_LIVE_PMC", "0") not in ("", "0"):
         args.live_pmc = True
     apply_preset(args)
@@ -269,8 +273,9 @@ def cpu_baseline(args, sino_dev, lc):
     dt = time.perf_counter() - t0
     its_full = (1.0 / dt) * (nzs / nz)
     return {"value": its_full, "unit": "iterations/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/tomo_oracle.c (OpenMP, {cores} threads): 1 outer {args.method} iteration on {nzs} of the "
-                      f"{nz} slices of the GPU leg's own sinogram ({dt:.1f} s), scaled by {nzs}/{nz}"}
+            "sample": f"oracle/tomo_oracle.c (OpenMP, {cores} threads): 1 outer {args.method} iteration of an {nzs}-slice 3D problem "
+                      f"({nzs} of the {nz} slices of the GPU leg's own sinogram, spread over z; the 3D TV prox sees {nzs} planes, i.e. "
+                      f"two z-faces per {nzs} planes instead of per {nz}) in {dt:.1f} s, scaled by {nzs}/{nz}"}
 
 
 def live_traffic(dom, args, n, nz, sub):
@@ -559,6 +564,18 @@ def measure(args, env):
                        "frac_lds_spec_2.4GHz": kb["frac_lds"], "frac_lds_sustained_2.03GHz": kb["frac_lds_sustained"],
                        "note": "north-star kernel; an LDS-gather kernel: 8 B of ds_read_b128 per voxel-angle update put its floor at "
                                "lds_floor_ms, 4-5x above its HBM time (docs/kernels/bp.md)"}
+        # ... and the forward projector's, the kernel that dominates configs[3] (826 of 1641 ms per ADMM iteration on one GPU)
+        roof_fp = None
+        if "fp" in kernels:
+            kf = kernels["fp"]
+            fp_tr, fp_src = committed_traffic("fp")
+            roof_fp = {"bound": "hbm", "kernel": "fp", "achieved": kf["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": kf["frac_hbm"], "traffic": fp_tr, "traffic_source": fp_src,
+                       "avg_launch_ms": kf["avg_ms"], "launches": kf["launches"],
+                       "bytes_per_launch": kf["compulsory_bytes_per_launch"], "updates_per_s": kf["updates_per_s"],
+                       "frac_lds_spec_2.4GHz": kf["frac_lds"], "frac_lds_sustained_2.03GHz": kf["frac_lds_sustained"],
+                       "note": "one forward projection = its stepping-class launches; an LDS-gather kernel like the back projector "
+                               "(8 B of ds_read_b128 per ray step), co-bound by VALU issue, staging 20-25 % of the call (docs/kernels/fp.md)"}
         units = args.steps if args.strong else args.steps * world
         what = (f"{nz_total} slices of {n}^2 split over {world} z-slab(s)" if args.strong
                 else f"{nz} slices of {n}^2 per GPU; slab-iterations/s over {world} z-slab(s)")
@@ -583,6 +600,8 @@ def measure(args, env):
         }
         if roof_bp is not None:
             line["roofline_bp"] = roof_bp
+        if roof_fp is not None:
+            line["roofline_fp"] = roof_fp
         if halo is not None:
             line["halo"] = halo
         # where the library put its TV scratch arena (docs/kernels/placement.md); "fast": False explains a PD_TV launch
@@ -598,6 +617,77 @@ def _lib_release(device):
     """Give the library's scratch arenas of this device back before a second workload is set up."""
     from tomobar_amd import _lib
     _lib.lib().tomo_release_scratch(int(device.index))
+
+
+def north_star_child(args, world, ns_test, gpu_bytes):
+    """Rank 0 only, after the headline: strong scaling of BASELINE configs[4] over `world` ranks as a child
+    `torch.distributed.run` in its own process group, under a wall-clock limit.  Returns the `north_star` block."""
+    import copy
+    import signal
+    from tomobar_amd.slab import slab_bounds
+    block = {"workload": "BASELINE configs[4], --strong", "how": "supervised child job (second torch.distributed.run)"}
+    ns = copy.copy(args)
+    for k in ("n", "nz", "angles", "os", "inner", "reg", "method", "ring"):
+        setattr(ns, k, None)
+    ns.config, ns.strong, ns.half = "cfg5", True, False
+    child_argv = ["--gpus", str(world), "--config", "cfg5", "--strong", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-pmc",
+                  "--no-north-star", "--backend", args.backend]
+    if ns_test:
+        ns.n, ns.nz, ns.angles, ns.inner = 192, 12 * world, 96, 6
+        child_argv += ["--n", "192", "--nz", str(12 * world), "--angles", "96", "--inner", "6"]
+    apply_preset(ns)
+    share = max(slab_bounds(ns.nz, world, r)[1] - slab_bounds(ns.nz, world, r)[0] for r in range(world))
+    need = footprint_bytes(ns, share)
+    block.update({"per_gpu_slices": share, "estimated_bytes_per_gpu": need})
+    if need >= 0.9 * gpu_bytes:
+        block["skipped"] = f"a {share}-slice slab needs ~{need / 1e9:.0f} GB of the GPU's {gpu_bytes / 1e9:.0f} GB"
+        return block
+    limit = float(os.environ.get("BENCH_NORTH_STAR_TIMEOUT", "900"))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+                        "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "TOMO_BENCH_ARGV", "BENCH_CONFIG", "BENCH_STRONG",
+                        "BENCH_NORTH_STAR", "BENCH_NORTH_STAR_TEST")
+           and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_", "NCCL_ASYNC"))}
+    env.update({"TOMO_BENCH_ARGV": json.dumps(child_argv), "TOMO_BENCH_CHILD": "1", "OMP_NUM_THREADS": env.get("OMP_NUM_THREADS", "1")})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)]
+    if os.environ.get("BENCH_NORTH_STAR_CMD"):   # test seam (tests/test_host_logic.py): a stand-in child command, JSON list
+        cmd = json.loads(os.environ["BENCH_NORTH_STAR_CMD"])
+    t0 = time.perf_counter()
+    try:
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    except OSError as e:
+        block["skipped"] = f"could not start the child job: {e!r}"[:300]
+        return block
+    try:
+        out, err = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)      # the child's own session: its launcher and every rank, nothing else
+        except OSError:
+            pass
+        out, err = proc.communicate()
+        block["skipped"] = f"child job killed after the {limit:.0f} s wall-clock limit (BENCH_NORTH_STAR_TIMEOUT)"
+        block["child_stderr_tail"] = (err or "")[-400:]
+        return block
+    block["child_wall_s"] = time.perf_counter() - t0
+    child_line = None
+    for ln in reversed((out or "").strip().splitlines()):
+        try:
+            cand = json.loads(ln)
+        except ValueError:
+            continue
+        if isinstance(cand, dict) and "metric" in cand:
+            child_line = cand
+            break
+    if proc.returncode != 0 or child_line is None:
+        block["skipped"] = f"child job exited with code {proc.returncode}" + ("" if child_line is not None else " without a JSON line")
+        block["child_stderr_tail"] = (err or "")[-400:]
+        return block
+    block.update({k: child_line[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config",
+                                             "roofline", "roofline_bp", "roofline_fp", "halo") if k in child_line})
+    return block
 
 
 def main():
@@ -672,52 +762,26 @@ def main():
     del sino
     # N > 1: the headline value above is what the contract asks for (weak scaling of the default workload unless flags /
     # BENCH_CONFIG say otherwise).  The north-star target is STRONG scaling of BASELINE configs[4] (2560^2 x 2160, 1800
-    # angles, OS 12, PD_TV + ring term): on request (--north-star / BENCH_NORTH_STAR=1) it is measured as a second, clearly
-    # separate block when every rank's share fits its GPU (it does from 4 GPUs on).  The block can only ADD to the line:
-    # the headline is persisted on stderr before the block starts, every rank proves it can allocate its share before any
-    # collective of the second workload is entered, and the ranks agree on that with one MIN-all-reduce.
+    # angles, OS 12, PD_TV + ring term).  It runs as a SUPERVISED CHILD JOB so that nothing it does can cost the headline:
+    # every rank finishes the headline workload, the line is persisted on stderr, the ranks leave their process group and
+    # give their GPU memory back; only then rank 0 starts a second `torch.distributed.run` of this script (--config cfg5
+    # --strong) under a hard wall-clock limit, kills its whole process group if the limit passes, and merges the child's JSON
+    # line into `north_star` -- or {"skipped": why} on a timeout / non-zero exit / a share that does not fit.
     ns_test = os.environ.get("BENCH_NORTH_STAR_TEST", "0") not in ("", "0")  # dry run of this block on a shared GPU, tiny shape
-    if world > 1 and args.north_star and (ns_test or not oversubscribed) and not (args.strong and args.config == "cfg5"):
-        import copy
+    ns_default = world >= 4 and not oversubscribed        # from 4 GPUs on every rank's share of configs[4] fits (<= 540 slices)
+    want_ns = (world > 1 and (args.north_star or ns_default) and not args.no_north_star and (ns_test or not oversubscribed)
+               and not (args.strong and args.config == "cfg5") and not os.environ.get("TOMO_BENCH_CHILD"))
+    if want_ns:
         if rank == 0:
-            print("[bench] headline (kept whatever the north-star block does): " + json.dumps(line), file=sys.stderr, flush=True)
-        block = {"workload": "BASELINE configs[4], --strong"}
-        ns = copy.copy(args)
-        for k in ("n", "nz", "angles", "os", "inner", "reg", "method", "ring"):
-            setattr(ns, k, None)
-        ns.config, ns.strong, ns.half, ns.steps, ns.warmup = "cfg5", True, False, 2, 1
-        if ns_test:
-            ns.n, ns.nz, ns.angles, ns.inner = 192, 12 * world, 96, 6
-        apply_preset(ns)
-        from tomobar_amd.slab import slab_bounds
-        share = max(slab_bounds(ns.nz, world, r)[1] - slab_bounds(ns.nz, world, r)[0] for r in range(world))
-        need = footprint_bytes(ns, share)
-        total_b = torch.cuda.mem_get_info(device)[1]
-        ok = 1 if need < 0.9 * total_b else 0
-        if ok:   # prove it: one allocation of the estimated footprint, freed again (an OOM here strands nobody)
-            try:
-                torch.cuda.empty_cache()
-                _lib_release(device)
-                probe = torch.empty(int(need), dtype=torch.uint8, device=device)
-                del probe
-                torch.cuda.empty_cache()
-            except Exception:  # noqa: BLE001
-                ok = 0
-        fits = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(fits, op=dist.ReduceOp.MIN)
-        block.update({"per_gpu_slices": share, "estimated_bytes_per_gpu": need})
-        if int(fits.item()) == 1:
-            try:
-                ns_line, _, _ = measure(ns, env)
-                if rank == 0:
-                    block.update({k: ns_line[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "scaling",
-                                                          "config", "roofline", "roofline_bp", "halo") if k in ns_line})
-            except Exception as e:  # noqa: BLE001 -- reported in the block; the headline is already on stderr
-                block["error"] = repr(e)[:300]
-        else:
-            block["skipped"] = f"a {share}-slice slab needs ~{need / 1e9:.0f} GB of the GPU's {total_b / 1e9:.0f} GB (or could not be allocated on some rank)"
+            print("[bench] headline (kept whatever the north-star child job does): " + json.dumps(line), file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        _lib_release(device)
+        dist.barrier()                     # every rank is past its timed region AND has given its GPU memory back
+        dist.destroy_process_group()
+        dist = None
         if rank == 0:
-            line["north_star"] = block
+            line["north_star"] = north_star_child(args, world, ns_test, torch.cuda.mem_get_info(device)[1])
     if rank == 0:
         print(json.dumps(line), file=json_out, flush=True)
     if dist is not None:

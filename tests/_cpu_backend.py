@@ -103,7 +103,10 @@ class OracleTools3D:
         r = self._bp(np.ascontiguousarray(_np(sino)), self._sub(os_index))
         return torch.from_numpy(r) if out is None else _put(out, r)
 
-    def residual(self, vol, b, w, fidelity, os_index, out, gathered=0):
+    def residual(self, vol, b, w, fidelity, os_index, out, gathered=0, robust=None):
+        if robust is not None:
+            self.residual(vol, b, w, fidelity, os_index, out, gathered)
+            return self.robust_apply(out, *robust)
         ax = self._fp(np.ascontiguousarray(_np(vol)), self._sub(os_index))
         idx = self._idx(os_index)
         bs = _np(b)[:, idx, :]
@@ -141,6 +144,10 @@ class OracleTools3D:
             ws = ws + ws_[:, a, :]
         q = wr / (ws + np.float32(beta))
         _put(res, ws_ * r - ws_ * q[:, None, :])
+
+    def robust_apply(self, res, mode, delta):
+        from oracle import tomo_oracle as O
+        return _put(res, O.robust_weight(_np(res), **{mode: delta}))
 
     def ring_update(self, r, r_old, r_x, lam, beta):
         v = _np(r).copy()

@@ -320,6 +320,57 @@ def test_bench_environment_overrides_and_north_star_footprint(monkeypatch):
     assert fits == {1: False, 2: False, 4: True, 8: True}, fits
 
 
+def test_north_star_child_job_is_supervised(monkeypatch, tmp_path):
+    """The north-star block of a multi-GPU run is a child job under a wall-clock limit: a child that hangs is killed with its
+    whole process group and reported as skipped, a child that fails is reported with its exit code, a child that prints a
+    bench line is merged -- in every case the caller (which has already persisted the headline) gets a block back."""
+    import json
+    import sys
+    import time
+    import bench
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    args = bench.parse()
+    py = sys.executable
+    # (1) hangs: killed after the limit, with the grandchild it spawned
+    marker = str(tmp_path / "grandchild_alive")
+    grand = tmp_path / "grand.py"
+    grand.write_text(f"import time\ntime.sleep(4)\nopen({marker!r}, 'w').write('alive')\n")
+    hang = tmp_path / "hang.py"
+    hang.write_text(f"import subprocess, sys, time\nsubprocess.Popen([sys.executable, {str(grand)!r}])\ntime.sleep(60)\n")
+    monkeypatch.setenv("BENCH_NORTH_STAR_CMD", json.dumps([py, str(hang)]))
+    monkeypatch.setenv("BENCH_NORTH_STAR_TIMEOUT", "1.5")
+    t0 = time.perf_counter()
+    block = bench.north_star_child(args, 8, False, 288e9)
+    assert time.perf_counter() - t0 < 20
+    assert "killed after the" in block["skipped"] and "wall-clock limit" in block["skipped"], block
+    assert block["per_gpu_slices"] == 270 and "value" not in block
+    # (2) fails
+    monkeypatch.setenv("BENCH_NORTH_STAR_TIMEOUT", "60")
+    monkeypatch.setenv("BENCH_NORTH_STAR_CMD", json.dumps([py, "-c", "import sys; print('boom', file=sys.stderr); sys.exit(3)"]))
+    block = bench.north_star_child(args, 8, False, 288e9)
+    assert "exited with code 3" in block["skipped"] and "boom" in block["child_stderr_tail"], block
+    # (3) succeeds: the child's JSON line (last line of its stdout that parses as a bench line) is merged; the child was told
+    #     its workload through TOMO_BENCH_ARGV and that it is a child (no nesting)
+    ok = ("import json, os; a = json.loads(os.environ['TOMO_BENCH_ARGV']); assert os.environ['TOMO_BENCH_CHILD'] == '1'; "
+          "assert 'RANK' not in os.environ and 'BENCH_CONFIG' not in os.environ; print('noise'); "
+          "print(json.dumps({'metric': 'fista_os_iterations_per_sec', 'value': 1.25, 'unit': 'iterations/s', 'n_gpus': 8, "
+          "'scaling': 'strong', 'config': {'argv': a}, 'ms_per_step': 800.0, 'steps': 2, 'warmup': 1}))")
+    monkeypatch.setenv("BENCH_NORTH_STAR_CMD", json.dumps([py, "-c", ok]))
+    monkeypatch.setenv("RANK", "0")                 # what a rank under the driver's launcher sees; must not leak into the child
+    monkeypatch.setenv("BENCH_CONFIG", "cfg2")
+    block = bench.north_star_child(args, 8, False, 288e9)
+    assert block["value"] == 1.25 and block["scaling"] == "strong" and "skipped" not in block, block
+    argv = block["config"]["argv"]
+    assert argv[:6] == ["--gpus", "8", "--config", "cfg5", "--strong", "--steps"] and "--no-north-star" in argv
+    # (4) a share that cannot fit is not even started
+    block = bench.north_star_child(args, 2, False, 288e9)
+    assert "needs ~" in block["skipped"] and block["per_gpu_slices"] == 1080
+    # the grandchild of (1) died with its group: it never wrote its marker
+    time.sleep(max(0.0, 5.0 - (time.perf_counter() - t0)))
+    assert not os.path.exists(marker)
+
+
 def test_oracle_thread_team_follows_the_usable_cpus(oracle, monkeypatch):
     """The oracle's OpenMP team is sized to the CPUs the process may use (affinity mask capped by the cgroup quota), not
     to the logical CPU count of the host."""

@@ -173,8 +173,11 @@ def _fista_worker(rank, world, port, case):
             d.update(ringGH_lambda=ring["lambda"], ringGH_accelerate=ring["accelerate"])
         if case["fid"] == "SWLS":
             d["beta_SWLS"] = 0.3
+        robust = case.get("robust", {})   # Huber / Student's-t re-weighting: element-wise, hence slab-local
+        for key, val in robust.items():
+            d[f"{key}_threshold"] = val
         if case["method"] == "FISTA":
-            want = O.fista(P, sino, 2, L_whole, True, full_reg, case["fid"], ring=ring, beta_swls=0.3)
+            want = O.fista(P, sino, 2, L_whole, True, full_reg, case["fid"], ring=ring, beta_swls=0.3, **robust)
             got = rt.FISTA(d, {"iterations": 2, "lipschitz_const": L_whole, "nonnegativity": True,
                                "recon_mask_radius": None}, reg)
         else:
@@ -194,6 +197,10 @@ FISTA_CASES = [
     dict(method="FISTA", nz=10, os=4, fid="PWLS", ring={"lambda": 1e-4, "accelerate": 3},
          reg=dict(method="PD_TV", regul_param=0.002, iterations=6)),
     dict(method="FISTA", nz=9, os=3, fid="SWLS", reg=None),
+    # robust data terms (Huber with the ring term, Student's t plain) in z-slab mode
+    dict(method="FISTA", nz=9, os=3, fid="PWLS", ring={"lambda": 1e-4, "accelerate": 3}, robust={"huber": 0.3},
+         reg=dict(method="PD_TV", regul_param=0.002, iterations=6)),
+    dict(method="FISTA", nz=8, os=2, fid="LS", robust={"studentst": 1.5}, reg=None),
     # ADMM + ROF_TV without subsets: what BASELINE configs[3] runs on 4 ranks
     dict(method="ADMM", nz=9, os=1, fid="LS", reg=dict(method="ROF_TV", regul_param=0.003, iterations=5, time_marching_step=0.002)),
     # vertical CoR component: ghost detector rows travel with every projector call (tomobar_amd.slab.extend_detector_rows)
@@ -204,7 +211,8 @@ FISTA_CASES = [
 
 
 @pytest.mark.parametrize("case", FISTA_CASES, ids=lambda c: f"{c['method']}-os{c['os']}-{c['fid']}-{(c['reg'] or {}).get('method')}"
-                         + ("-vertical-cor" if c.get("vshift") else "") + ("-ring" if c.get("ring") else ""))
+                         + ("-vertical-cor" if c.get("vshift") else "") + ("-ring" if c.get("ring") else "")
+                         + "".join(f"-{k}" for k in c.get("robust", {})))
 def test_slab_reconstruction_drivers_match_whole_volume(case):
     """world-2 gloo run of RecToolsIRCuPy.powermethod / FISTA / ADMM with ``rt.slab`` set: power-method all-reduce, PWLS
     maximum all-reduce and the slab proximal step together; the oracle stands in for the C-ABI library at the projector /

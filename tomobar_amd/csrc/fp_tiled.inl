@@ -162,7 +162,11 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
     auto prefetch = [&](int k0) {
 #pragma unroll
         for (int r = 0; r < KC; ++r) {
-            const int k = min(k0 + r, n - 1);
+            // readfirstlane: the row index is wave-uniform, but in the 16-angle instantiation the compiler carries the chunk
+            // counter in a VECTOR register, builds the four row descriptors there and wraps every one of the 16 staging loads of a
+            // chunk in a waterfall loop (4 v_readfirstlane + 2 v_cmp_eq_u64 + exec juggling per load: 3.4 extra VALU per read pair
+            // in a kernel bound by VALU issue; found in the ISA in round 6 -- tools/kisa.sh + kmix.py: 549 -> 4xx VALU per chunk)
+            const int k = __builtin_amdgcn_readfirstlane(min(k0 + r, n - 1));
             const int lo4 = __builtin_amdgcn_readfirstlane(win_lo[k]) * 4;
             const int wid = (k0 + r < n) ? __builtin_amdgcn_readfirstlane(win_wid[k]) : 0;
             const size_t rowoff = (size_t)k * (size_t)n;

@@ -1,11 +1,11 @@
 """Small fixed workloads for rocprofv3 --pmc passes (one kernel class per invocation, few launches).
-usage: python tools/pmc_probe.py <what> [N] [NZ] [NA]   what in {pdtv0,pdtv1,pdtv0h,roftv,bp0,bp1,bp3,bpp,bpq,fp,fpq,momentum,fourier}"""
+usage: python tools/pmc_probe.py <what> [N] [NZ] [NA]   what in {pdtv0,pdtv1,pdtv0h,roftv,bp0,bp1,bp3,bpp,bpq,fp,fp4,fpq,momentum,fourier}"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-if os.environ.get("PMC_PROBE", "0") != "0" or (len(sys.argv) > 1 and sys.argv[1].rstrip("h") in ("pdtv1", "pdtv2", "pdtv21", "bp1", "bp2", "bp3", "bpp")):
+if os.environ.get("PMC_PROBE", "0") != "0" or (len(sys.argv) > 1 and sys.argv[1].rstrip("h") in ("pdtv1", "pdtv2", "pdtv21", "bp1", "bp2", "bp3", "bpp", "fp4")):
     os.environ.setdefault("TOMO_MI355X_FLAVOUR", "dev")   # measurement switches / A-B variants: libtomo_mi355x_dev.so
 from tomobar_amd import ops
 from tomobar_amd.projector import HipTools3D
@@ -64,6 +64,8 @@ else:
         for _ in range(3):
             H.backward(sino, None, out=out)
     else:
+        if what == "fp4":   # dev flavour: the whole-row form without the per-angle lane multipliers (pixel = lane, round 5)
+            ops.set_variant("fp", 4)
         for _ in range(2):
             H.forward(vol, None, out=sino)
 torch.cuda.synchronize()
