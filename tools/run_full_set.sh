@@ -1,6 +1,6 @@
-# full measurement set of a source state: usage  bash tools/run_full_set.sh <tag>   (round 5: r5z)
+# full measurement set of a source state: usage  bash tools/run_full_set.sh <tag>   (round 5: r5z, round 6: r6z)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-T=${1:-r5z}; O=gpurun_out/$T; mkdir -p $O
+T=${1:-r6z}; O=gpurun_out/$T; mkdir -p $O
 timeout 2700 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu --no-pmc > $O/bench_prof_line.json 2> $O/bench_prof.err
@@ -21,5 +21,15 @@ timeout 900 python bench.py --config cfg3-share --steps 2 --warmup 1 > $O/bench_
 timeout 900 python bench.py --config cfg5-share --steps 2 --warmup 1 > $O/bench_cfg5_share.json 2> $O/bench_cfg5_share.err
 timeout 1500 python bench.py --config cfg3 --steps 3 --warmup 1 > $O/bench_cfg3_full.json 2> $O/bench_cfg3_full.err
 timeout 300 python tools/kernel_bench.py 1024 1024 75 3 > $O/kernel_bench_1024.txt 2>&1
+# the 2048^3-class line as a driver that only varies --gpus reaches it, under rocprofv3 as well (round 6)
+BENCH_CONFIG=cfg3 rocprofv3 --kernel-trace --stats -d $O/prof3 -o cfg3 -- python bench.py --steps 2 --warmup 1 --no-cpu --no-pmc > $O/bench_cfg3_prof_line.json 2> $O/bench_cfg3_prof.err
+DB3=$(find $O/prof3 -name "*.db" | head -1)
+python tools/rocpd_summary.py "$DB3" $O/bench_cfg3_kernel_stats.txt | head -8
+find $O/prof3 -type f -size +1M -delete
+# multi-rank dry runs on the one GPU (gloo transport, "oversubscribed": functional only) against the final library
+timeout 300 python tools/rccl_preflight.py --gpus 2 --n 1024 --nz 64 --reps 3 > $O/rccl_preflight_dryrun.json 2> $O/rccl_preflight_dryrun.err
+timeout 600 python bench.py --gpus 2 --strong --n 512 --nz 128 --angles 360 --steps 2 --warmup 1 > $O/bench_2ranks_strong_dryrun.json 2> $O/bench_2ranks_strong_dryrun.err
+timeout 600 python bench.py --gpus 2 --n 512 --nz 128 --angles 360 --steps 2 --warmup 1 > $O/bench_2ranks_weak_dryrun.json 2> $O/bench_2ranks_weak_dryrun.err
+BENCH_NORTH_STAR_TEST=1 timeout 900 python bench.py --gpus 2 --north-star --n 512 --nz 128 --angles 360 --steps 2 --warmup 1 > $O/bench_2ranks_north_star_child_dryrun.json 2> $O/bench_2ranks_north_star_child_dryrun.err
 tail -4 $O/pytest.log; tail -1 $O/smoke.log; cat $O/pmc_update.log
-for f in bench_default bench_20_steps bench_exact_tv bench_half bench_cfg1 bench_cfg3_share bench_cfg5_share bench_cfg3_full; do cut -c1-150 $O/$f.json; done
+for f in bench_default bench_20_steps bench_exact_tv bench_half bench_cfg1 bench_cfg3_share bench_cfg5_share bench_cfg3_full bench_cfg3_prof_line rccl_preflight_dryrun bench_2ranks_strong_dryrun bench_2ranks_weak_dryrun bench_2ranks_north_star_child_dryrun; do cut -c1-150 $O/$f.json; done
