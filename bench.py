@@ -654,9 +654,20 @@ def north_star_child(args, world, ns_test, gpu_bytes):
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)]
     if os.environ.get("BENCH_NORTH_STAR_CMD"):   # test seam (tests/test_host_logic.py): a stand-in child command, JSON list
         cmd = json.loads(os.environ["BENCH_NORTH_STAR_CMD"])
+    def own_session_dies_with_parent():
+        # its own session (= process group: one killpg reaches the launcher and every rank) and PR_SET_PDEATHSIG: should this
+        # rank be killed by whoever supervises IT, the child launcher gets SIGTERM and takes its ranks down -- no orphaned job
+        # keeps the GPUs of the next run busy
+        os.setsid()
+        try:
+            C.CDLL(None).prctl(1, int(signal.SIGTERM))
+        except Exception:  # noqa: BLE001
+            pass
+
     t0 = time.perf_counter()
     try:
-        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                preexec_fn=own_session_dies_with_parent)
     except OSError as e:
         block["skipped"] = f"could not start the child job: {e!r}"[:300]
         return block

@@ -714,3 +714,28 @@ def test_tv_random_shapes(oracle, ops, seed, flavour):
     if flavour == "shipped" and half:
         assert np.array_equal(got, want_pd), ("pd default, binary16 duals", shape, iters, mtv, nn)
     assert rel(got, want_pd) < (2e-4 if half else 1e-5), ("pd relaxed", shape, iters, half, mtv, nn, rel(got, want_pd))
+
+
+def test_residual_buffer_must_match_the_contexts_layout(oracle):
+    """The residual layout is state on the projector context; a buffer of the other layout would be written past its end (nz not
+    a multiple of 4) or misread.  The host class refuses it instead of handing it to the C-ABI, which cannot see buffer sizes."""
+    P, H = make_pair(oracle, (6, 36, 40, 22, 0.5, 3))
+    rng = np.random.default_rng(5)
+    x = dev(rng.random((P.nz, P.n, P.n)).astype(np.float32))
+    b = dev(rng.random((P.nz, P.na, P.nu)).astype(np.float32))
+    planar = H.residual_buffer(0)
+    H.set_residual_layout("zquad")
+    try:
+        quad = H.residual_buffer(0)
+        assert quad.numel() > planar.numel()          # 6 slices -> 2 quads = 8 slice rows
+        with pytest.raises(ValueError):
+            H.residual(x, b, None, "LS", 0, planar)   # a second driver / thread still holding a planar buffer
+        H.residual(x, b, None, "LS", 0, quad)
+        with pytest.raises(ValueError):
+            H.grad_step(planar, x, torch.empty_like(x), 1e-3, True, 0)
+    finally:
+        H.set_residual_layout("planar")
+    with pytest.raises(ValueError):
+        H.grad_step(quad, x, torch.empty_like(x), 1e-3, True, 0)
+    H.residual(x, b, None, "LS", 0, planar)
+    assert np.array_equal(host(H.residual_as_planar(quad, 0)), host(planar))

@@ -274,6 +274,17 @@ class HipTools3D:
         return torch.empty((n // (4 * self.nu * self.subset_size(os_index)), self.subset_size(os_index), self.nu, 4),
                            dtype=torch.float32, device=self._device)
 
+    def _check_residual(self, res, os_index):
+        """The C-ABI cannot see buffer sizes; the context's residual layout is state another thread or stream sharing this
+        object may have flipped (a driver holds "zquad" around its loop): a buffer of the other layout would be written
+        past its end when nz % 4 != 0, or misread.  Refuse anything but a buffer of the current layout's size and rank."""
+        want = int(self._lib.tomo_ctx_residual_elems(self._ctx, self._sub(os_index)))
+        quad = self.residual_layout() == "zquad"
+        if res.numel() != want or (res.dim() == 4) != quad:
+            raise ValueError(f"residual buffer of {res.numel()} floats / rank {res.dim()} does not match the context's current "
+                             f"'{self.residual_layout()}' layout ({want} floats): take it from residual_buffer() after "
+                             "set_residual_layout(), and do not share one projector object between drivers running concurrently")
+
     def residual_as_planar(self, res, os_index=None) -> torch.Tensor:
         """A [detY, angles, detX] copy of a residual buffer whatever layout it was written in (diagnostics / tests)."""
         if res.dim() == 3:
@@ -285,6 +296,8 @@ class HipTools3D:
         """out = w_s*(A_s vol - b_s) (LS/PWLS) or 1 - b_s/max(A_s vol, 1e-8) (KL); ``gathered`` bit0/bit1: b / w is
         already the subset's array instead of the full sinogram.  ``robust`` = ("huber" | "studentst", threshold):
         the Huber / Student's-t re-weighting of the residual in the same epilogue (include/tomo_mi355x.h)."""
+        if self._vshift is None:
+            self._check_residual(out, os_index)
         if robust is not None:
             mode, delta = robust
             if self._vshift is not None:
@@ -369,12 +382,16 @@ class HipTools3D:
         self._chk(self._lib.tomo_ctx_invalidate(self._ctx))
 
     def grad_step(self, res, x_t, x_out, l_inv, nonneg, os_index):
+        if self._vshift is None:
+            self._check_residual(res, os_index)
         res = self._adjoint_in(res, os_index)
         with torch.cuda.device(self._device):
             self._chk(self._lib.tomo_bp3d_fista(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(x_t), ops.ptr(x_out),
                                             float(l_inv), int(bool(nonneg)), ops.stream_ptr(x_t)))
 
     def grad_step_momentum(self, res, x_t, x_old_then_x, l_inv, beta, nonneg, os_index):
+        if self._vshift is None:
+            self._check_residual(res, os_index)
         res = self._adjoint_in(res, os_index)
         with torch.cuda.device(self._device):
             self._chk(self._lib.tomo_bp3d_fista_momentum(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(x_t),
@@ -382,6 +399,8 @@ class HipTools3D:
                                                      int(bool(nonneg)), ops.stream_ptr(x_t)))
 
     def admm_z_update(self, res, z, x, u, zu_out, tau, rho, relax_on, one_minus_alpha, alpha, nonneg, os_index):
+        if self._vshift is None:
+            self._check_residual(res, os_index)
         res = self._adjoint_in(res, os_index)
         with torch.cuda.device(self._device):
             self._chk(self._lib.tomo_bp3d_admm(self._ctx, self._sub(os_index), ops.ptr(res), ops.ptr(z), ops.ptr(x),
