@@ -39,7 +39,22 @@ def one_case(seed, O, torch, RecToolsIRCuPy, ops, scale=1):
         cor = rng.uniform(-2, 2, na)
     else:
         cor = np.stack([rng.uniform(-2, 2, na), (0.0 if two_d else 1.0) * rng.uniform(-1.5, 1.5, na)], axis=1)
-    fid = str(rng.choice(["LS", "PWLS", "KL"])) if method == "FISTA" else ("KL" if method == "OSEM" else str(rng.choice(["LS", "PWLS"])))
+    fid = str(rng.choice(["LS", "PWLS", "KL", "SWLS"])) if method == "FISTA" else ("KL" if method == "OSEM" else str(rng.choice(["LS", "PWLS"])))
+    # round 6: the data terms of the reference's removed class in the mix (FISTA only): Group-Huber ring offsets, Huber / Student's t
+    extra, okw = {}, {}
+    if method == "FISTA" and fid in ("LS", "PWLS") and rng.integers(0, 4) == 0:
+        lam, acc = float(rng.choice([1e-4, 1e-3])), float(rng.integers(2, 9))
+        extra.update(ringGH_lambda=lam, ringGH_accelerate=acc)
+        okw["ring"] = {"lambda": lam, "accelerate": acc}
+    if method == "FISTA" and fid != "KL" and rng.integers(0, 3) == 0:
+        if rng.integers(0, 2):
+            dlt = float(np.round(rng.uniform(0.05, 1.0), 3))
+            extra["huber_threshold"], okw["huber"] = dlt, dlt
+        else:
+            dlt = float(np.round(rng.uniform(0.5, 3.0), 3))
+            extra["studentst_threshold"], okw["studentst"] = dlt, dlt
+    if fid == "SWLS":
+        extra["beta_SWLS"], okw["beta_swls"] = 0.2, 0.2
     regm = rng.choice(["none", "PD_TV", "ROF_TV"])
     reg, full_reg = None, None
     if regm != "none":
@@ -68,7 +83,7 @@ def one_case(seed, O, torch, RecToolsIRCuPy, ops, scale=1):
                 iters=iters, mask=mask, warm=bool(warm), two_d=bool(two_d))
     b_pad = O.pad_detector(sino, pad)
     if method == "FISTA":
-        want = O.fista(P, b_pad, iters, Lc, nonneg, full_reg, fid, x0=x0)
+        want = O.fista(P, b_pad, iters, Lc, nonneg, full_reg, fid, x0=x0, **okw)
     elif method == "ADMM":
         want = O.admm(P, b_pad, iters, Lc, 1.0, 1.6, nonneg, full_reg, fid, x0=x0)
     else:
@@ -89,7 +104,9 @@ def one_case(seed, O, torch, RecToolsIRCuPy, ops, scale=1):
     desc["order"] = order
     ops.set_variant("pdtv", 22)
     rt = RecToolsIRCuPy(det, pad, None if two_d else nz, cor, angles, det, 0, os_n if os_n > 1 else None)
-    d = {"projection_data": torch.from_numpy(np.ascontiguousarray(data)).cuda(), "data_axes_labels_order": order, "data_fidelity": fid}
+    d = {"projection_data": torch.from_numpy(np.ascontiguousarray(data)).cuda(), "data_axes_labels_order": order, "data_fidelity": fid,
+         **extra}
+    desc["extra"] = extra
     a = {"iterations": iters, "lipschitz_const": Lc, "nonnegativity": nonneg, "recon_mask_radius": mask}
     if warm:
         a["initialise"] = torch.from_numpy(x0).cuda()
