@@ -739,3 +739,33 @@ def test_residual_buffer_must_match_the_contexts_layout(oracle):
         H.grad_step(quad, x, torch.empty_like(x), 1e-3, True, 0)
     H.residual(x, b, None, "LS", 0, planar)
     assert np.array_equal(host(H.residual_as_planar(quad, 0)), host(planar))
+
+
+@pytest.mark.parametrize("g", [(5, 840, 1000, 40, 3.3, 1),      # one 1024-thread tile, 24 dead pixels, rays leaving the volume sideways
+                               (3, 1100, 901, 45, -7.25, 3),     # detector narrower than the volume, tile of 960 threads, subsets
+                               (6, 700, 1800, 24, "vec", 1),     # two tiles of 960 of a detector much wider than the volume
+                               (2, 1000, 768, 33, 0.0, 1)])      # the smallest tile that takes the lane multipliers
+@pytest.mark.parametrize("variant", _v(0, 4))
+def test_forward_projection_lane_multipliers_odd_wide_detectors(oracle, ops, g, variant):
+    """The per-angle lane -> pixel multipliers of the whole-row form (round 6; from 768-pixel tiles up) on detector widths that are
+    not a multiple of the tile, with dead pixels, clipped windows and per-angle offsets: forward projection and the residual epilogue
+    in both layouts, bit for bit (variant 4, dev flavour: the same form with pixel = lane)."""
+    P, H = make_pair(oracle, g)
+    ops.set_variant("fp", variant)
+    rng = np.random.default_rng(12)
+    vol = rng.standard_normal((P.nz, P.n, P.n)).astype(np.float32)
+    b = rng.standard_normal((P.nz, P.na, P.nu)).astype(np.float32)
+    for s in ([None] if P.os_number == 1 else [0, P.os_number - 1]):
+        want = P.fp(vol, s)
+        got = host(H.forward(dev(vol), s))
+        assert "whole-row" in H.kernel_path("fp"), H.kernel_path("fp")
+        assert np.array_equal(got, want), (g, s, float(np.abs(got - want).max()))
+        idx = slice(None) if s is None else P.subsets[s]
+        for layout in ("planar", "zquad"):
+            H.set_residual_layout(layout)
+            try:
+                res = H.residual_buffer(s)
+                H.residual(dev(vol), dev(b), None, "LS", s, res)
+                assert np.array_equal(host(H.residual_as_planar(res, s)), (want - b[:, idx]).astype(np.float32)), (g, s, layout)
+            finally:
+                H.set_residual_layout("planar")
