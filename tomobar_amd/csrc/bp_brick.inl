@@ -121,8 +121,10 @@ __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
             const float f01 = fmaf(x0, t.cs, fmaf(y1, t.sn, off)), f11 = fmaf(x1, t.cs, fmaf(y1, t.sn, off));
             // clamp so that the int conversion and the offsets below stay in range whatever the geometry
             const float lo = fminf(fminf(f00, f10), fminf(f01, f11));
-            umin_s[buf][tid] = (int)fminf(fmaxf(floorf(lo), -1.0e6f), 1.0e6f);
-            if constexpr (ZQ) ang_s[buf][tid] = make_float4(t.cs, t.sn, off, 0.0f);
+            const int um = (int)fminf(fmaxf(floorf(lo), -1.0e6f), 1.0e6f);
+            umin_s[buf][tid] = um;
+            // (the window origin rides in the record's fourth word: the sampling gets it with the same ds_read_b128)
+            if constexpr (ZQ) ang_s[buf][tid] = make_float4(t.cs, t.sn, off, __int_as_float(um));
         }
     };
 
@@ -201,15 +203,19 @@ __global__ __launch_bounds__(256) void bp_brick_kernel(BpArgs a)
         }
         auto sample = [&](int aa) {
             float t_cs, t_sn, off;
+            int um;
             if constexpr (ZQ) {
+                // (cos, sin, detector offset, window origin) as ONE ds_read_b128 (4 LDS cycles per wave).  Round 6: with three words
+                // used the compiler emitted a ds_read_b96, which takes 8, and the origin came from a separate ds_read_b32 -- together
+                // an eighth of the tap reads' cycles on the pipe that bounds this kernel
                 const float4 an = ang_s[buf][aa];
-                t_cs = an.x; t_sn = an.y; off = an.z;
+                t_cs = an.x; t_sn = an.y; off = an.z; um = __float_as_int(an.w);
             } else {
                 const tomo_angle_t t = a.tab[a0 + aa];
-                t_cs = t.cs; t_sn = t.sn; off = half_u - t.cor;
+                t_cs = t.cs; t_sn = t.sn; off = half_u - t.cor; um = umin_s[buf][aa];
             }
             // the window origin is wave-uniform: fold it into a scalar byte offset so that a tap address is one v_lshl_add
-            int ab = __builtin_amdgcn_readfirstlane((aa * (BB_ZQ * BB_PITCH) - umin_s[buf][aa]) * 16);
+            int ab = __builtin_amdgcn_readfirstlane((aa * (BB_ZQ * BB_PITCH) - um) * 16);
             asm("" : "+s"(ab));  // opaque: otherwise the *16 is factored back out (a second VALU op per tap)
             const char *tb = reinterpret_cast<const char *>(tile);
 #pragma unroll
