@@ -216,7 +216,9 @@ __global__ __launch_bounds__(BT) void fp_tiled_kernel(FpTiledArgs a)
             for (int i = 0; i < M; ++i) asm volatile("" ::"v"(pre[i].x), "v"(pre[i].y), "v"(pre[i].z), "v"(pre[i].w));
         }
         __syncthreads();  // chunk c staged; every wave is past the sampling of chunk c-1 (other buffer)
-        const int k0 = c * KC;
+        // readfirstlane: (float)row below is a VALU conversion, and from it some instantiations pull the whole chain of wave-uniform
+        // row / chunk counters into vector registers (then every use of them costs v_min / v_add / v_readfirstlane instead of SALU)
+        const int k0 = __builtin_amdgcn_readfirstlane(c * KC);
         if (stage && c + 1 < nchunks) prefetch(k0 + KC);  // in flight while chunk c is sampled
 #pragma unroll
         for (int r = 0; r < KC; ++r) {
